@@ -1,0 +1,656 @@
+// TEST INFRASTRUCTURE — not part of the shipped render path.
+//
+// f64 CPU restatement of the reference's `render` hot path, kept deliberately
+// close to the reference's structure (recursive trace, per-node intersection
+// lists, sort-then-sweep CSG) so that it can be read side by side with it.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
+//
+// Parity status: the reference holds no image-level fixture for this path and
+// cannot be built in this environment (no Rust toolchain), so image-level parity
+// is UNPINNED.  What pins this file: the reference's own unit-test facts
+// (tests/test_oracle_kats.py restates them) and analytic closed forms.
+//
+// Reference map (all under /root/reference/src):
+//   vecmath helpers            vecmath.rs:7-34 (+ crate vecmath 0.3.1 definitions)
+//   Transform apply            transform.rs:9-41
+//   Intersection               primitives.rs:104-168
+//   Operator::intersect        primitives.rs:177-187, 253-315
+//   Sphere/Cube/Cylinder/Cone/Plane  primitives.rs:349-420, 462-565, 587-743, 765-913, 945-1006
+//   lights                     lights.rs:42-120
+//   trace / render_pixels      raytracer.rs:30-147
+//   quantiser                  raytracer.rs:21-25
+// Scene construction (tokenizer, parser, evaluator, transform builders) is the
+// host front-end in rust-raytracer_amd/csrc/gml_front.*; surfaces are evaluated
+// the way the reference does it, by re-entering that evaluator per hit
+// (evaluator.rs:776-792).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../rust-raytracer_amd/csrc/gml_front.hpp"
+
+namespace oracle {
+
+using Vec3 = std::array<double, 3>;
+
+// ---- vecmath.rs:7-28 (crate functions restated: component-wise ops, dot summed
+// left to right, normalize multiplies by 1/sqrt)
+static inline Vec3 add(Vec3 a, Vec3 b) { return {a[0] + b[0], a[1] + b[1], a[2] + b[2]}; }
+static inline Vec3 sub(Vec3 a, Vec3 b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+static inline Vec3 mul(Vec3 a, double s) { return {a[0] * s, a[1] * s, a[2] * s}; }
+static inline Vec3 neg(Vec3 a) { return {-a[0], -a[1], -a[2]}; }
+static inline double dot(Vec3 a, Vec3 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline double length(Vec3 a) { return std::sqrt(dot(a, a)); }
+static inline Vec3 normalize(Vec3 a) { return mul(a, 1.0 / std::sqrt(dot(a, a))); }
+static inline Vec3 cmul(Vec3 a, Vec3 b) { return {a[0] * b[0], a[1] * b[1], a[2] * b[2]}; }
+
+// ---- transform.rs:9-36
+struct Xf {
+  double m[4][4], inv[4][4];
+  static Vec3 apply(const double (*M)[4], Vec3 p, double w) {
+    Vec3 r;
+    for (int i = 0; i < 3; i++) r[i] = M[i][0] * p[0] + M[i][1] * p[1] + M[i][2] * p[2] + M[i][3] * w;
+    return r;
+  }
+  Vec3 transform_point(Vec3 p) const { return apply(m, p, 1.0); }
+  Vec3 inv_transform_point(Vec3 p) const { return apply(inv, p, 1.0); }
+  Vec3 inv_transform_vector(Vec3 p) const { return apply(inv, p, 0.0); }
+  Vec3 transform_normal(Vec3 v) const {  // transpose(inv_m) * [v,0]
+    Vec3 r;
+    for (int i = 0; i < 3; i++) r[i] = inv[0][i] * v[0] + inv[1][i] * v[1] + inv[2][i] * v[2] + inv[3][i] * 0.0;
+    return r;
+  }
+};
+
+enum class IType : uint8_t { Entry, Exit };
+
+struct Primitive;
+
+// primitives.rs:110-168
+struct Intersection {
+  double odistance, distance;
+  Vec3 rp, rd;
+  const Primitive* prim;
+  IType t, original_t;
+  int64_t face;
+  static Intersection make(double scale, double od, Vec3 rp, Vec3 rd, const Primitive* p, IType t, int64_t face) {
+    return Intersection{od, scale * od, rp, rd, p, t, t, face};
+  }
+  bool switched() const { return t != original_t; }
+  Vec3 get_opos() const { return add(rp, mul(rd, odistance)); }
+};
+using IList = std::vector<Intersection>;
+
+struct Surf { Vec3 color; double kd, ks, n; };
+
+struct NodeO {
+  virtual IList intersect(Vec3 raypos, Vec3 raydir) const = 0;
+  virtual ~NodeO() {}
+};
+
+struct Primitive : NodeO {
+  Xf tr;
+  gml::ValuePtr surface;
+  gml::PrimType type;
+  // get_surface: per-type (face,u,v) mapping, then the closure call
+  virtual bool uv(Vec3 o, int64_t face, double* u, double* v) const = 0;
+  virtual bool normal_obj(Vec3 o, int64_t face, Vec3* n) const = 0;
+  Surf get_surface(gml::Evaluator& ev, Vec3 opos, int64_t face) const {
+    double u, v;
+    if (!uv(opos, face, &u, &v)) throw gml::GmlError("InvalidFace");
+    Surf s;
+    ev.call_surface(*surface, face, u, v, &s.color, &s.kd, &s.ks, &s.n);
+    return s;
+  }
+  Vec3 get_normal(Vec3 p, int64_t face) const {
+    Vec3 n;
+    if (!normal_obj(p, face, &n)) throw gml::GmlError("InvalidFace");
+    return normalize(tr.transform_normal(n));
+  }
+  // common prologue, primitives.rs:350-354 and analogues
+  void to_object(Vec3 raypos, Vec3 raydir, double* scale, Vec3* d, Vec3* p) const {
+    Vec3 td = tr.inv_transform_vector(raydir);
+    *scale = 1.0 / length(td);
+    *d = mul(td, *scale);
+    *p = tr.inv_transform_point(raypos);
+  }
+};
+
+// ---- primitives.rs:349-420
+struct Sphere : Primitive {
+  IList intersect(Vec3 raypos, Vec3 raydir) const override {
+    double scale; Vec3 d, p;
+    to_object(raypos, raydir, &scale, &d, &p);
+    double s = dot(neg(p), d);
+    double lsq = dot(p, p);
+    if (s < 0.0 && lsq > 1.0) return {};
+    double msq = lsq - s * s;
+    if (msq > 1.0) return {};
+    double q = std::sqrt(1.0 - msq);
+    double t1 = s + q, t2 = s - q;
+    if (t1 > t2) std::swap(t1, t2);
+    IList ts;
+    if (t1 > 0.0) ts.push_back(Intersection::make(scale, t1, p, d, this, IType::Entry, 0));
+    if (t2 > 0.0) ts.push_back(Intersection::make(scale, t2, p, d, this, IType::Exit, 0));
+    return ts;
+  }
+  bool uv(Vec3 o, int64_t face, double* u, double* v) const override {
+    *v = (o[1] + 1.0) / 2.0;
+    *u = std::atan2(o[0], o[2]);
+    return face == 0;
+  }
+  bool normal_obj(Vec3 o, int64_t face, Vec3* n) const override { *n = o; return face == 0; }
+};
+
+// ---- primitives.rs:430-565
+static const Vec3 kCubeNormals[6] = {{0, 0, -1}, {0, 0, 1}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+static const int64_t kSlabs[3][2] = {{3, 2}, {4, 5}, {1, 0}};
+
+struct Cube : Primitive {
+  IList intersect(Vec3 raypos, Vec3 raydir) const override {
+    double scale; Vec3 d, rp;
+    to_object(raypos, raydir, &scale, &d, &rp);
+    const double eps = 1e-15;
+    bool has_min = false, has_max = false;
+    double tmin = 0, tmax = 0;
+    int64_t fmin = 0, fmax = 0;
+    Vec3 p = sub({0.5, 0.5, 0.5}, rp);
+    for (int i = 0; i < 3; i++) {
+      int64_t face1 = kSlabs[i][0], face2 = kSlabs[i][1];
+      double e = p[i], f = d[i];
+      if (std::fabs(f) > eps) {
+        double t1 = (e + 0.5) / f, t2 = (e - 0.5) / f;
+        if (t1 > t2) { std::swap(t1, t2); std::swap(face1, face2); }
+        if (!(has_min && tmin >= t1)) { has_min = true; tmin = t1; fmin = face1; }
+        if (!(has_max && tmax <= t2)) { has_max = true; tmax = t2; fmax = face2; }
+        if (tmin > tmax) return {};
+        if (tmax < 0.0) return {};
+      } else if (-e - 0.5 > 0.0 || -e + 0.5 < 0.0) {
+        return {};
+      }
+    }
+    IList ts;
+    if (has_min && tmin > 0.0) ts.push_back(Intersection::make(scale, tmin, rp, d, this, IType::Entry, fmin));
+    if (has_max && tmax > 0.0) ts.push_back(Intersection::make(scale, tmax, rp, d, this, IType::Exit, fmax));
+    return ts;
+  }
+  bool uv(Vec3 o, int64_t face, double* u, double* v) const override {
+    switch (face) {
+      case 0: case 1: *u = o[0]; *v = o[1]; return true;
+      case 2: case 3: *u = o[2]; *v = o[1]; return true;
+      case 4: case 5: *u = o[0]; *v = o[2]; return true;
+      default: return false;
+    }
+  }
+  bool normal_obj(Vec3, int64_t face, Vec3* n) const override {
+    if (face < 0 || face >= 6) return false;
+    *n = kCubeNormals[face];
+    return true;
+  }
+};
+
+// (t, face) pairs compare lexicographically, as Rust tuples do
+struct TF { double t; int64_t face; };
+static inline bool tf_gt(TF a, TF b) { return a.t != b.t ? a.t > b.t : a.face > b.face; }
+static inline bool tf_lt(TF a, TF b) { return a.t != b.t ? a.t < b.t : a.face < b.face; }
+
+// roots of a t^2 + b t + c with face 0, primitives.rs:592-606 / 778-792
+static bool solve_quadratic(double a, double b, double c, TF* r1, TF* r2) {
+  double sq = b * b - 4.0 * a * c;
+  if (sq < 0.0) return false;
+  double root = std::sqrt(sq);
+  TF t1{(-b - root) / (2.0 * a), 0}, t2{(-b + root) / (2.0 * a), 0};
+  if (tf_gt(t1, t2)) std::swap(t1, t2);
+  *r1 = t1; *r2 = t2;
+  return true;
+}
+
+// ---- primitives.rs:587-743
+struct Cylinder : Primitive {
+  static void solve_plane(double py, double dy, TF* a, TF* b) {
+    double dinv = 1.0 / dy;
+    double t1 = -py * dinv, t2 = (-py + 1.0) * dinv;
+    TF tt1{t1, 2}, tt2{t2, 1};
+    if (t1 > t2) std::swap(tt1, tt2);
+    *a = tt1; *b = tt2;
+  }
+  IList intersect(Vec3 in_raypos, Vec3 in_raydir) const override {
+    double scale; Vec3 raydir, raypos;
+    to_object(in_raypos, in_raydir, &scale, &raydir, &raypos);
+    const double eps = 1e-7;
+    double px = raypos[0], py = raypos[1], pz = raypos[2];
+    double dx = raydir[0], dy = raydir[1], dz = raydir[2];
+    TF tmin, tmax;
+    if (std::fabs(dy) + eps >= 1.0) {
+      double frsd = 1.0 - px * px - pz * pz;
+      if (frsd < 0.0) return {};
+      solve_plane(py, dy, &tmin, &tmax);
+    } else if (std::fabs(dy) < eps) {
+      if (py < 0.0 || py > 1.0) return {};
+      if (!solve_quadratic(dx * dx + dz * dz, 2.0 * (px * dx + pz * dz), px * px + pz * pz - 1.0, &tmin, &tmax)) return {};
+    } else {
+      TF tc1, tc2;
+      if (!solve_quadratic(dx * dx + dz * dz, 2.0 * (px * dx + pz * dz), px * px + pz * pz - 1.0, &tc1, &tc2)) return {};
+      TF tp1, tp2;
+      solve_plane(py, dy, &tp1, &tp2);
+      tmin = tp1; tmax = tp2;
+      if (tf_gt(tc1, tmin)) tmin = tc1;
+      if (tf_lt(tc2, tmax)) tmax = tc2;
+      if (tmin.t > tmax.t) return {};
+      if (tmax.t < 0.0) return {};
+    }
+    IList it;
+    if (tmin.t > 0.0) it.push_back(Intersection::make(scale, tmin.t, raypos, raydir, this, IType::Entry, tmin.face));
+    if (tmax.t > 0.0) it.push_back(Intersection::make(scale, tmax.t, raypos, raydir, this, IType::Exit, tmax.face));
+    return it;
+  }
+  bool uv(Vec3 o, int64_t face, double* u, double* v) const override {
+    switch (face) {
+      case 0: *u = std::atan2(o[0], o[2]); *v = o[1]; return true;
+      case 1: case 2: *u = (o[0] + 1.0) / 2.0; *v = (o[2] + 1.0) / 2.0; return true;
+      default: return false;
+    }
+  }
+  bool normal_obj(Vec3 p, int64_t face, Vec3* n) const override {
+    switch (face) {
+      case 0: *n = {p[0], 0.0, p[2]}; return true;
+      case 1: *n = {0.0, 1.0, 0.0}; return true;
+      case 2: *n = {0.0, -1.0, 0.0}; return true;
+      default: return false;
+    }
+  }
+};
+
+// ---- primitives.rs:765-913
+struct Cone : Primitive {
+  IList intersect(Vec3 in_raypos, Vec3 in_raydir) const override {
+    double scale; Vec3 raydir, raypos;
+    to_object(in_raypos, in_raydir, &scale, &raydir, &raypos);
+    double px = raypos[0], py = raypos[1], pz = raypos[2];
+    double dx = raydir[0], dy = raydir[1], dz = raydir[2];
+    TF tcmin, tcmax;
+    if (!solve_quadratic(dx * dx + dz * dz - dy * dy, 2.0 * (px * dx + pz * dz - py * dy),
+                         px * px + pz * pz - py * py, &tcmin, &tcmax))
+      return {};
+    TF ts[3];
+    int n = 0;
+    double cminy = py + tcmin.t * dy, cmaxy = py + tcmax.t * dy;
+    if (0.0 <= cminy && cminy <= 1.0) ts[n++] = tcmin;
+    if (0.0 <= cmaxy && cmaxy <= 1.0) ts[n++] = tcmax;
+    if (n == 0) return {};
+    if (n == 1) {
+      // exactly one hit on the mantle: the other one is on the base cap
+      double tp = (-py + 1.0) / dy;
+      ts[1] = TF{tp, 1};
+      // two-element sort with partial_cmp(..).unwrap_or(Less): swap iff second<first or unordered
+      if (!(ts[1].t >= ts[0].t)) std::swap(ts[0], ts[1]);
+    }
+    IList tr;
+    if (ts[0].t > 0.0) tr.push_back(Intersection::make(scale, ts[0].t, raypos, raydir, this, IType::Entry, ts[0].face));
+    if (ts[1].t > 0.0) tr.push_back(Intersection::make(scale, ts[1].t, raypos, raydir, this, IType::Exit, ts[1].face));
+    return tr;
+  }
+  bool uv(Vec3 o, int64_t face, double* u, double* v) const override {
+    switch (face) {
+      case 0: *u = std::atan2(o[0], o[2]); *v = o[1]; return true;
+      case 1: *u = (o[0] + 1.0) / 2.0; *v = (o[2] + 1.0) / 2.0; return true;
+      default: return false;
+    }
+  }
+  bool normal_obj(Vec3 p, int64_t face, Vec3* n) const override {
+    switch (face) {
+      case 0: *n = {p[0], -p[1], p[2]}; return true;
+      case 1: *n = {0.0, 1.0, 0.0}; return true;
+      default: return false;
+    }
+  }
+};
+
+// ---- primitives.rs:945-1006
+struct Plane : Primitive {
+  IList intersect(Vec3 in_raypos, Vec3 in_raydir) const override {
+    const Vec3 np = {0.0, 1.0, 0.0};
+    double scale; Vec3 raydir, raypos;
+    to_object(in_raypos, in_raydir, &scale, &raydir, &raypos);
+    double denom = dot(np, raydir);
+    if (std::fabs(denom) < 1e-7) return {};
+    double t = -dot(np, raypos) / denom;
+    if (t < 0.0) return {};
+    return {Intersection::make(scale, t, raypos, raydir, this, denom > 0.0 ? IType::Exit : IType::Entry, 0)};
+  }
+  bool uv(Vec3 o, int64_t face, double* u, double* v) const override { *u = o[0]; *v = o[2]; return face == 0; }
+  bool normal_obj(Vec3, int64_t face, Vec3* n) const override { *n = {0.0, 1.0, 0.0}; return face == 0; }
+};
+
+// ---- primitives.rs:170-316
+struct Operator : NodeO {
+  std::unique_ptr<NodeO> obj1, obj2;
+  gml::Rule rule;
+  bool apply_rule(bool a, bool b) const {
+    switch (rule) {
+      case gml::Rule::Union: return a || b;
+      case gml::Rule::Intersect: return a && b;
+      default: return a && !b;
+    }
+  }
+  IList intersect(Vec3 raypos, Vec3 raydir) const override {
+    int inside1 = 0, inside2 = 0;
+    bool inside = apply_rule(inside1 > 0, inside2 > 0);
+    IList o1 = obj1->intersect(raypos, raydir);
+    IList o2 = obj2->intersect(raypos, raydir);
+    struct Ev { const Intersection* i; int obj; };
+    std::vector<Ev> evs;
+    evs.reserve(o1.size() + o2.size());
+    for (auto& i : o1) evs.push_back({&i, 1});
+    for (auto& i : o2) evs.push_back({&i, 2});
+    // sort_unstable_by(partial_cmp.unwrap_or(Less)).  Written as the insertion
+    // sort Rust's sort uses for short slices: order-preserving on equal distances
+    // (obj1's events stay ahead of obj2's).  For longer slices Rust's tie order is
+    // formally unspecified; this restatement keeps the same rule at every length.
+    auto is_less = [](const Ev& a, const Ev& b) { return !(a.i->distance >= b.i->distance); };
+    for (size_t k = 1; k < evs.size(); k++) {
+      if (is_less(evs[k], evs[k - 1])) {
+        Ev tmp = evs[k];
+        size_t j = k;
+        do { evs[j] = evs[j - 1]; j--; } while (j > 0 && is_less(tmp, evs[j - 1]));
+        evs[j] = tmp;
+      }
+    }
+    IList res;
+    double prevt = 0.0;
+    for (auto& e : evs) {
+      const Intersection& i = *e.i;
+      if (i.t == IType::Entry) { if (e.obj == 1) inside1 += 1; else inside2 += 1; }
+      else { if (e.obj == 1) inside1 -= 1; else inside2 -= 1; }
+      bool newinside = apply_rule(inside1 > 0, inside2 > 0);
+      if (inside && !newinside) {
+        if ((i.distance - prevt) < 1e-10) {
+          if (!res.empty()) res.pop_back();
+        } else {
+          Intersection ic = i; ic.t = IType::Exit; res.push_back(ic);
+        }
+      }
+      if (!inside && newinside) {
+        Intersection ic = i; ic.t = IType::Entry; prevt = ic.distance; res.push_back(ic);
+      }
+      inside = newinside;
+    }
+    return res;
+  }
+};
+
+// ---- lights.rs:42-120
+static void light_direction(const gml::Light& l, Vec3 pos, Vec3* dir, bool* has_dist, double* dist) {
+  if (l.kind == gml::Light::Directional) { *dir = l.dir; *has_dist = false; *dist = 0; return; }
+  Vec3 d = sub(l.pos, pos);
+  double dl = length(d);
+  *dir = mul(d, 1.0 / dl);
+  *has_dist = true;
+  *dist = l.kind == gml::Light::Point ? length(d) : dl;
+}
+static Vec3 light_intensity(const gml::Light& l, Vec3 pos) {
+  if (l.kind == gml::Light::Directional) return l.color;
+  Vec3 d = sub(l.pos, pos);
+  double dsq = dot(d, d);
+  if (l.kind == gml::Light::Point) return mul(l.color, 100.0 / (99.0 + dsq));
+  double invlend = 1.0 / std::sqrt(dsq);
+  double cosangle = -dot(d, l.dir) * invlend;
+  if (cosangle < l.coscutoff) return {0.0, 0.0, 0.0};
+  double i = std::pow(dot(l.dir, mul(d, -invlend)), l.exp);
+  return mul(l.color, i * 100.0 / (99.0 + dsq));
+}
+
+struct Counters { uint64_t primary = 0, shadow = 0, reflect = 0; };
+
+struct Scene {
+  std::unique_ptr<NodeO> root;
+  std::vector<gml::LightPtr> lights;
+  Vec3 amb;
+};
+
+// ---- raytracer.rs:30-42
+static Vec3 get_ambient(Vec3 c, Vec3 ia, double kd) { return mul(cmul(ia, c), kd); }
+static Vec3 get_specular(Vec3 ic, Vec3 lightdir, Vec3 sn, Vec3 pos, Vec3 raypos, double n) {
+  Vec3 halfway = normalize(add(lightdir, normalize(sub(raypos, pos))));
+  double sp = dot(sn, halfway);
+  if (sp > 0.0) return mul(ic, std::pow(sp, n));
+  return {0.0, 0.0, 0.0};
+}
+
+// ---- raytracer.rs:44-111
+static Vec3 trace(const Scene& sc, gml::Evaluator& ev, Counters& cnt, int64_t depth, Vec3 raypos, Vec3 raydir) {
+  IList i = sc.root->intersect(raypos, raydir);
+  if (i.empty()) return {0.0, 0.0, 0.0};
+  const Intersection& isect = i[0];
+  if (isect.t == IType::Exit) return {0.0, 0.0, 0.0};
+  const Primitive* primitive = isect.prim;
+  Vec3 opos = isect.get_opos();
+  Surf s = primitive->get_surface(ev, opos, isect.face);
+  Vec3 c = get_ambient(s.color, sc.amb, s.kd);
+  Vec3 diffuse = {0, 0, 0}, specular = {0, 0, 0};
+  Vec3 pos = primitive->tr.transform_point(opos);
+  Vec3 normal = primitive->get_normal(opos, isect.face);
+  if (isect.switched()) normal = neg(normal);
+  for (auto& light : sc.lights) {
+    Vec3 lightdir; bool has_ld; double ld;
+    light_direction(*light, pos, &lightdir, &has_ld, &ld);
+    double df = dot(normal, lightdir);
+    if (df > 0.0) {
+      Vec3 poseps = add(pos, mul(lightdir, 1e-7));
+      cnt.shadow++;
+      IList lighti = sc.root->intersect(poseps, lightdir);
+      bool do_lights = lighti.empty();
+      if (!do_lights && has_ld && ld < lighti[0].distance) do_lights = true;
+      if (do_lights) {
+        Vec3 ic = cmul(s.color, light_intensity(*light, pos));
+        if (s.kd > 0.0) diffuse = add(diffuse, mul(ic, df));
+        if (s.ks > 0.0) specular = add(specular, get_specular(ic, lightdir, normal, pos, raypos, s.n));
+      }
+    }
+  }
+  Vec3 diff = mul(diffuse, s.kd);
+  Vec3 spec = mul(specular, s.ks);
+  c = add(c, add(diff, spec));
+  if (s.ks > 0.0 && depth > 0) {
+    Vec3 refl = normalize(sub(raydir, mul(normal, 2.0 * dot(raydir, normal))));
+    Vec3 poseps = add(pos, mul(refl, 1e-7));
+    cnt.reflect++;
+    Vec3 rc = trace(sc, ev, cnt, depth - 1, poseps, refl);
+    return add(c, mul(cmul(rc, s.color), s.ks));
+  }
+  return c;
+}
+
+// ---- raytracer.rs:21-25
+static inline uint8_t quantise(double p) {
+  double v = 255.0 * std::fmin(std::fmax(p, 0.0), 1.0);
+  if (!(v == v)) return 0;
+  return (uint8_t)v;  // v in [0,255]: truncation
+}
+
+struct Builder : gml::TreeVisitor {
+  std::vector<std::unique_ptr<NodeO>> stack;
+  void leaf(gml::PrimType prim, const gml::ValuePtr& surface, const gml::Transform& t) override {
+    std::unique_ptr<Primitive> p;
+    switch (prim) {
+      case gml::PrimType::Sphere: p.reset(new Sphere); break;
+      case gml::PrimType::Cube: p.reset(new Cube); break;
+      case gml::PrimType::Cylinder: p.reset(new Cylinder); break;
+      case gml::PrimType::Cone: p.reset(new Cone); break;
+      default: p.reset(new Plane); break;
+    }
+    p->type = prim;
+    p->surface = surface;
+    std::memcpy(p->tr.m, t.m.m, sizeof(p->tr.m));
+    std::memcpy(p->tr.inv, t.inv_m.m, sizeof(p->tr.inv));
+    stack.push_back(std::move(p));
+  }
+  void op(gml::Rule rule) override {
+    auto o = std::make_unique<Operator>();
+    o->obj2 = std::move(stack.back()); stack.pop_back();
+    o->obj1 = std::move(stack.back()); stack.pop_back();
+    o->rule = rule;
+    stack.push_back(std::move(o));
+  }
+};
+
+struct Program {
+  std::vector<gml::RenderCall> calls;
+  std::string error;
+};
+
+// raytracer.rs:121-147 over rows y0, y0+ystep, ... < y1 (all rows: 0, h, 1)
+static void render_rows(const gml::RenderCall& rc, int64_t w, int64_t h, int64_t depth, int64_t y0, int64_t y1,
+                        int64_t ystep, int nthreads, uint8_t* rgb8, double* rgbf, uint64_t counts[3]) {
+  Scene sc;
+  Builder b;
+  gml::walk_postfix(rc.scene, b);
+  sc.root = std::move(b.stack.back());
+  sc.lights = rc.lights;
+  sc.amb = rc.amb;
+  const Vec3 raypos = {0.0, 0.0, -1.0};
+  const double fov_rad = rc.fov * (3.14159265358979323846 / 180.0);
+  const double w_world = 2.0 * std::tan(0.5 * fov_rad);
+  const double h_world = (double)h * w_world / (double)w;
+  const double c_x = -0.5 * w_world, c_y = 0.5 * h_world;
+  const double pw = w_world / (double)w;
+  std::vector<int64_t> rows;
+  for (int64_t y = y0; y < y1; y += ystep) rows.push_back(y);
+  std::atomic<size_t> next{0};
+  std::vector<Counters> cnts((size_t)std::max(1, nthreads));
+  auto worker = [&](int tid) {
+    gml::Evaluator ev(nullptr);
+    Counters& cnt = cnts[(size_t)tid];
+    for (;;) {
+      size_t ri = next.fetch_add(1);
+      if (ri >= rows.size()) break;
+      const double y = (double)rows[ri];
+      for (int64_t ix = 0; ix < w; ix++) {
+        const double x = (double)ix;
+        Vec3 dir = {c_x + (x + 0.5) * pw, c_y - (y + 0.5) * pw, -raypos[2]};
+        Vec3 raydir = normalize(dir);
+        cnt.primary++;
+        Vec3 px = trace(sc, ev, cnt, depth, raypos, raydir);
+        size_t o = (ri * (size_t)w + (size_t)ix) * 3;
+        if (rgbf) { rgbf[o] = px[0]; rgbf[o + 1] = px[1]; rgbf[o + 2] = px[2]; }
+        if (rgb8) { rgb8[o] = quantise(px[0]); rgb8[o + 1] = quantise(px[1]); rgb8[o + 2] = quantise(px[2]); }
+      }
+    }
+  };
+  if (nthreads <= 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+  }
+  counts[0] = counts[1] = counts[2] = 0;
+  for (auto& c : cnts) { counts[0] += c.primary; counts[1] += c.shadow; counts[2] += c.reflect; }
+}
+
+}  // namespace oracle
+
+// ------------------------------------------------------------------ C interface
+extern "C" {
+
+// Evaluates a GML file (with includes) and records every `render` call.
+// Returns a handle, or NULL with *err filled (caller passes a buffer).
+void* oracle_open(const char* path, char* err, int errlen) {
+  auto* p = new oracle::Program;
+  try {
+    std::string text = gml::preprocess_file(path);
+    gml::run_with_big_stack([&] {
+      gml::Evaluator ev([&](const gml::RenderCall& rc) { p->calls.push_back(rc); });
+      gml::Env env;
+      gml::Stack st;
+      ev.run(text, env, st);
+    });
+  } catch (std::exception& e) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+// Same, from program text (no include processing).
+void* oracle_open_text(const char* text, char* err, int errlen) {
+  auto* p = new oracle::Program;
+  try {
+    std::string t(text);
+    gml::run_with_big_stack([&] {
+      gml::Evaluator ev([&](const gml::RenderCall& rc) { p->calls.push_back(rc); });
+      gml::Env env;
+      gml::Stack st;
+      ev.run(t, env, st);
+    });
+  } catch (std::exception& e) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+void oracle_close(void* h) { delete (oracle::Program*)h; }
+int oracle_num_renders(void* h) { return (int)((oracle::Program*)h)->calls.size(); }
+
+// out = {w, h, depth}; fov in *fov
+int oracle_render_params(void* h, int idx, int64_t out[3], double* fov) {
+  auto* p = (oracle::Program*)h;
+  if (idx < 0 || idx >= (int)p->calls.size()) return -1;
+  out[0] = p->calls[(size_t)idx].w; out[1] = p->calls[(size_t)idx].h; out[2] = p->calls[(size_t)idx].depth;
+  *fov = p->calls[(size_t)idx].fov;
+  return 0;
+}
+
+// Renders rows y0, y0+ystep, ... (< y1) of render call `idx` at size w x h and
+// recursion depth `depth` (pass the values from oracle_render_params to keep the
+// program's own).  Row k of the output is image row y0 + k*ystep.  rgb8 / rgbf
+// may be NULL.  counts = {primary, shadow, reflect}.
+int oracle_render_rows(void* h, int idx, int64_t w, int64_t hh, int64_t depth, int64_t y0, int64_t y1, int64_t ystep,
+                       int nthreads, uint8_t* rgb8, double* rgbf, uint64_t counts[3], char* err, int errlen) {
+  auto* p = (oracle::Program*)h;
+  if (idx < 0 || idx >= (int)p->calls.size()) return -1;
+  try {
+    oracle::render_rows(p->calls[(size_t)idx], w, hh, depth, y0, y1, ystep, nthreads, rgb8, rgbf, counts);
+  } catch (std::exception& e) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what());
+    return -2;
+  }
+  return 0;
+}
+
+// Single-call helpers used by the known-answer tests -------------------------
+
+// Intersects one untransformed-then-translated primitive (type as gml::PrimType)
+// with a ray; returns the number of hits, writing (is_exit, distance, face) triples.
+int oracle_kat_intersect(int prim_type, const double translate[3], const double scale3[3], const double raypos[3],
+                         const double raydir[3], double* out, int max_hits) {
+  gml::Transform t;
+  t.scale(scale3[0], scale3[1], scale3[2]);
+  t.translate(translate[0], translate[1], translate[2]);
+  oracle::Builder b;
+  b.leaf((gml::PrimType)prim_type, nullptr, t);
+  auto l = b.stack.back()->intersect({raypos[0], raypos[1], raypos[2]}, {raydir[0], raydir[1], raydir[2]});
+  int n = 0;
+  for (auto& i : l) {
+    if (n >= max_hits) break;
+    out[n * 3 + 0] = i.t == oracle::IType::Exit ? 1.0 : 0.0;
+    out[n * 3 + 1] = i.distance;
+    out[n * 3 + 2] = (double)i.face;
+    n++;
+  }
+  return n;
+}
+
+uint8_t oracle_kat_quantise(double v) { return oracle::quantise(v); }
+
+}  // extern "C"
