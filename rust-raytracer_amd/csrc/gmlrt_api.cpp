@@ -1,0 +1,345 @@
+// C ABI of include/gmlrt.h: argument checking, scene handles, the in-process
+// multi-GPU driver (one host thread per GPU, interleaved row tiles, final gather
+// into the caller's framebuffer) and the GML program front-end handle.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gmlrt.h"
+#include "gml_front.hpp"
+#include "gmlrt_device.hpp"
+#include "gmlrt_scene.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+std::mutex g_mu;
+int g_n_gpus = 0;  // 0 = not initialised
+
+}  // namespace
+
+struct gmlrt_scene {
+  gmlrt::DeviceScene dev;
+};
+
+struct gmlrt_program {
+  struct Call {
+    gmlrt_params params;
+    std::string file;
+    std::vector<uint8_t> blob;
+  };
+  std::vector<Call> calls;
+};
+
+extern "C" {
+
+const char* gmlrt_strerror(int status) {
+  switch (status) {
+    case GMLRT_OK: return "ok";
+    case GMLRT_ERR_INVALID_ARG: return "invalid argument";
+    case GMLRT_ERR_BAD_BLOB: return "scene blob failed validation";
+    case GMLRT_ERR_NO_DEVICE: return "no usable GPU";
+    case GMLRT_ERR_HIP: return "HIP runtime call failed";
+    case GMLRT_ERR_GML: return "GML program error";
+    case GMLRT_ERR_UNSUPPORTED_SURFACE: return "surface function outside the supported bytecode subset";
+    case GMLRT_ERR_IO: return "I/O error";
+    case GMLRT_ERR_SCENE_TOO_LARGE: return "scene too large";
+    case GMLRT_ERR_NOT_INITIALISED: return "gmlrt_init has not been called";
+    default: return "unknown status";
+  }
+}
+
+const char* gmlrt_last_error(void) { return g_last_error.c_str(); }
+
+int64_t gmlrt_part_rows(int64_t height, int32_t tile_rows, int32_t part, int32_t nparts) {
+  if (height <= 0) return 0;
+  if (nparts <= 1) return height;
+  if (tile_rows <= 0 || part < 0 || part >= nparts) return 0;
+  const int64_t n_tiles = (height + tile_rows - 1) / tile_rows;
+  int64_t rows = 0;
+  for (int64_t t = part; t < n_tiles; t += nparts) {
+    const int64_t y0 = t * tile_rows;
+    rows += (y0 + tile_rows <= height) ? tile_rows : (height - y0);
+  }
+  return rows;
+}
+
+int gmlrt_part_row_index(int64_t height, int32_t tile_rows, int32_t part, int32_t nparts, int64_t* rows_out) {
+  if (!rows_out || height < 0) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_part_row_index: bad argument");
+  if (nparts <= 1) {
+    for (int64_t y = 0; y < height; y++) rows_out[y] = y;
+    return GMLRT_OK;
+  }
+  if (tile_rows <= 0 || part < 0 || part >= nparts) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_part_row_index: bad partition");
+  const int64_t n_tiles = (height + tile_rows - 1) / tile_rows;
+  int64_t k = 0;
+  for (int64_t t = part; t < n_tiles; t += nparts)
+    for (int64_t y = t * tile_rows; y < (t + 1) * tile_rows && y < height; y++) rows_out[k++] = y;
+  return GMLRT_OK;
+}
+
+int gmlrt_device_count(void) {
+  int n = 0;
+  std::string e = gmlrt::dev_count(&n);
+  if (!e.empty()) { g_last_error = e; return 0; }
+  return n;
+}
+
+int gmlrt_init(int n_gpus) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int avail = 0;
+  std::string e = gmlrt::dev_count(&avail);
+  if (!e.empty() || avail <= 0) return fail(GMLRT_ERR_NO_DEVICE, e.empty() ? "no HIP device visible" : e);
+  if (n_gpus < 0 || n_gpus > avail) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_init: more GPUs requested than visible");
+  g_n_gpus = n_gpus == 0 ? avail : n_gpus;
+  return GMLRT_OK;
+}
+
+void gmlrt_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_n_gpus = 0;
+}
+
+static int check_params(const gmlrt_params* p) {
+  if (!p) return fail(GMLRT_ERR_INVALID_ARG, "params is NULL");
+  if (p->width <= 0 || p->height <= 0 || p->width > (1 << 20) || p->height > (1 << 20))
+    return fail(GMLRT_ERR_INVALID_ARG, "image size out of range");
+  if (p->depth < 0 || p->depth > 1024) {
+    // a negative depth never bounces (raytracer.rs:100 tests depth > 0); treat it as 0 below
+    if (p->depth > 1024) return fail(GMLRT_ERR_INVALID_ARG, "depth above 1024");
+  }
+  if (p->nparts > 1 && (p->tile_rows <= 0 || p->part < 0 || p->part >= p->nparts))
+    return fail(GMLRT_ERR_INVALID_ARG, "bad row partition");
+  return GMLRT_OK;
+}
+
+int gmlrt_scene_create(const void* blob, size_t blob_bytes, int device, gmlrt_scene** out) {
+  if (!out) return fail(GMLRT_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  std::string v = gmlrt::validate_blob(blob, blob_bytes);
+  if (!v.empty()) return fail(GMLRT_ERR_BAD_BLOB, v);
+  int avail = 0;
+  std::string e = gmlrt::dev_count(&avail);
+  if (!e.empty() || avail <= 0) return fail(GMLRT_ERR_NO_DEVICE, e.empty() ? "no HIP device visible" : e);
+  if (device < 0 || device >= avail) return fail(GMLRT_ERR_INVALID_ARG, "device index out of range");
+  auto s = std::make_unique<gmlrt_scene>();
+  e = gmlrt::dev_scene_create(blob, blob_bytes, device, &s->dev);
+  if (!e.empty()) {
+    gmlrt::dev_scene_destroy(&s->dev);
+    return fail(GMLRT_ERR_HIP, e);
+  }
+  *out = s.release();
+  return GMLRT_OK;
+}
+
+void gmlrt_scene_destroy(gmlrt_scene* s) {
+  if (!s) return;
+  gmlrt::dev_scene_destroy(&s->dev);
+  delete s;
+}
+
+int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64, void* hip_stream,
+                        gmlrt_stats* stats) {
+  if (!s || !d_rgb8) return fail(GMLRT_ERR_INVALID_ARG, "scene or output pointer is NULL");
+  int rc = check_params(params);
+  if (rc != GMLRT_OK) return rc;
+  gmlrt_params p = *params;
+  if (p.depth < 0) p.depth = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  gmlrt_stats st;
+  std::memset(&st, 0, sizeof(st));
+  std::string e = gmlrt::dev_render(&s->dev, p, d_rgb8, d_rgbf64, hip_stream, &st);
+  if (!e.empty()) return fail(GMLRT_ERR_HIP, e);
+  st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  st.n_gpus = 1;
+  if (stats) *stats = st;
+  return GMLRT_OK;
+}
+
+int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params, uint8_t* rgb8, double* rgbf64,
+                 gmlrt_stats* stats) {
+  if (!rgb8) return fail(GMLRT_ERR_INVALID_ARG, "rgb8 is NULL");
+  int rc = check_params(params);
+  if (rc != GMLRT_OK) return rc;
+  int n_gpus;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    n_gpus = g_n_gpus;
+  }
+  if (n_gpus <= 0) return fail(GMLRT_ERR_NOT_INITIALISED, "call gmlrt_init first");
+  std::string v = gmlrt::validate_blob(blob, blob_bytes);
+  if (!v.empty()) return fail(GMLRT_ERR_BAD_BLOB, v);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int64_t w = params->width, h = params->height;
+  const int32_t tile_rows = params->tile_rows > 0 ? params->tile_rows : 8;
+  // no point in giving a GPU nothing to do
+  const int64_t n_tiles = (h + tile_rows - 1) / tile_rows;
+  if ((int64_t)n_gpus > n_tiles) n_gpus = (int)n_tiles;
+
+  struct PerGpu {
+    std::string err;
+    gmlrt_stats st;
+    std::vector<uint8_t> rgb8;
+    std::vector<double> rgbf;
+    std::vector<int64_t> rows;
+  };
+  std::vector<PerGpu> per((size_t)n_gpus);
+  auto work = [&](int g) {
+    PerGpu& P = per[(size_t)g];
+    std::memset(&P.st, 0, sizeof(P.st));
+    gmlrt_params p = *params;
+    if (p.depth < 0) p.depth = 0;
+    p.tile_rows = tile_rows;
+    p.part = g;
+    p.nparts = n_gpus;
+    const int64_t rows = gmlrt_part_rows(h, tile_rows, g, n_gpus);
+    P.rows.resize((size_t)rows);
+    gmlrt_part_row_index(h, tile_rows, g, n_gpus, P.rows.data());
+    gmlrt::DeviceScene ds;
+    void *d8 = nullptr, *df = nullptr;
+    do {
+      P.err = gmlrt::dev_scene_create(blob, blob_bytes, g, &ds);
+      if (!P.err.empty()) break;
+      const size_t n8 = (size_t)rows * (size_t)w * 3;
+      P.err = gmlrt::dev_alloc(g, n8, &d8);
+      if (!P.err.empty()) break;
+      if (rgbf64) {
+        P.err = gmlrt::dev_alloc(g, n8 * sizeof(double), &df);
+        if (!P.err.empty()) break;
+      }
+      P.err = gmlrt::dev_render(&ds, p, d8, df, nullptr, &P.st);
+      if (!P.err.empty()) break;
+      P.rgb8.resize(n8);
+      P.err = gmlrt::dev_copy_to_host(g, P.rgb8.data(), d8, n8);
+      if (!P.err.empty()) break;
+      if (rgbf64) {
+        P.rgbf.resize(n8);
+        P.err = gmlrt::dev_copy_to_host(g, P.rgbf.data(), df, n8 * sizeof(double));
+      }
+    } while (false);
+    gmlrt::dev_free(g, d8);
+    gmlrt::dev_free(g, df);
+    gmlrt::dev_scene_destroy(&ds);
+  };
+  if (n_gpus == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpus; g++) th.emplace_back(work, g);
+    for (auto& t : th) t.join();
+  }
+  gmlrt_stats total;
+  std::memset(&total, 0, sizeof(total));
+  for (auto& P : per) {
+    if (!P.err.empty()) return fail(GMLRT_ERR_HIP, P.err);
+    // the final gather: each GPU's rows go to their place in the caller's framebuffer
+    const size_t row8 = (size_t)w * 3;
+    for (size_t k = 0; k < P.rows.size(); k++) {
+      std::memcpy(rgb8 + (size_t)P.rows[k] * row8, P.rgb8.data() + k * row8, row8);
+      if (rgbf64) std::memcpy(rgbf64 + (size_t)P.rows[k] * row8, P.rgbf.data() + k * row8, row8 * sizeof(double));
+    }
+    total.rays_primary += P.st.rays_primary;
+    total.rays_shadow += P.st.rays_shadow;
+    total.rays_reflect += P.st.rays_reflect;
+    total.leaf_tests += P.st.leaf_tests;
+    if (P.st.kernel_ms > total.kernel_ms) total.kernel_ms = P.st.kernel_ms;
+  }
+  total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  total.n_gpus = (uint32_t)n_gpus;
+  if (stats) *stats = total;
+  return GMLRT_OK;
+}
+
+int gmlrt_write_ppm(const char* path, const uint8_t* rgb8, int64_t w, int64_t h) {
+  if (!path || !rgb8 || w <= 0 || h <= 0) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_write_ppm: bad argument");
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(GMLRT_ERR_IO, std::string("cannot create ") + path);
+  bool ok = std::fprintf(f, "P6 %lld %lld 255\n", (long long)w, (long long)h) > 0;
+  const size_t n = (size_t)w * (size_t)h * 3;
+  ok = ok && std::fwrite(rgb8, 1, n, f) == n;
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? GMLRT_OK : fail(GMLRT_ERR_IO, std::string("short write to ") + path);
+}
+
+// ------------------------------------------------------------------ GML programs
+static int program_open(const std::string& text, gmlrt_program** out) {
+  auto prog = std::make_unique<gmlrt_program>();
+  int rc = GMLRT_OK;
+  std::string msg;
+  try {
+    gml::run_with_big_stack([&] {
+      gml::Evaluator ev([&](const gml::RenderCall& rc_) {
+        gmlrt_program::Call c;
+        std::memset(&c.params, 0, sizeof(c.params));
+        for (int i = 0; i < 3; i++) c.params.amb[i] = rc_.amb[(size_t)i];
+        c.params.depth = rc_.depth;
+        c.params.fov_deg = rc_.fov;
+        c.params.width = rc_.w;
+        c.params.height = rc_.h;
+        c.params.tile_rows = 8;
+        c.params.part = 0;
+        c.params.nparts = 1;
+        c.file = rc_.file;
+        c.blob = gmlrt::flatten_scene(rc_);
+        prog->calls.push_back(std::move(c));
+      });
+      gml::Env env;
+      gml::Stack st;
+      ev.run(text, env, st);
+    });
+  } catch (gmlrt::UnsupportedSurface& e) {
+    rc = GMLRT_ERR_UNSUPPORTED_SURFACE;
+    msg = e.what();
+  } catch (std::exception& e) {
+    rc = GMLRT_ERR_GML;
+    msg = e.what();
+  }
+  if (rc != GMLRT_OK) return fail(rc, msg);
+  *out = prog.release();
+  return GMLRT_OK;
+}
+
+int gmlrt_program_open_file(const char* path, gmlrt_program** out) {
+  if (!path || !out) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_program_open_file: NULL argument");
+  *out = nullptr;
+  std::string text;
+  try {
+    text = gml::preprocess_file(path);
+  } catch (std::exception& e) {
+    return fail(GMLRT_ERR_IO, e.what());
+  }
+  return program_open(text, out);
+}
+
+int gmlrt_program_open_text(const char* gml_text, gmlrt_program** out) {
+  if (!gml_text || !out) return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_program_open_text: NULL argument");
+  *out = nullptr;
+  return program_open(gml_text, out);
+}
+
+void gmlrt_program_close(gmlrt_program* p) { delete p; }
+
+int gmlrt_program_num_renders(const gmlrt_program* p) { return p ? (int)p->calls.size() : 0; }
+
+int gmlrt_program_render_call(const gmlrt_program* p, int idx, gmlrt_params* params, const char** filename,
+                              const void** blob, size_t* blob_bytes) {
+  if (!p || idx < 0 || idx >= (int)p->calls.size()) return fail(GMLRT_ERR_INVALID_ARG, "render call index out of range");
+  const auto& c = p->calls[(size_t)idx];
+  if (params) *params = c.params;
+  if (filename) *filename = c.file.c_str();
+  if (blob) *blob = c.blob.data();
+  if (blob_bytes) *blob_bytes = c.blob.size();
+  return GMLRT_OK;
+}
+
+}  // extern "C"

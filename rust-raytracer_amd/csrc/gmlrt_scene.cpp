@@ -1,0 +1,705 @@
+#include "gmlrt_scene.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+#include "gmlrt_surface_vm.h"
+
+namespace gmlrt {
+
+// ============================================================== symbolic values
+namespace {
+
+struct Expr;
+using ExprP = std::shared_ptr<Expr>;
+struct Expr {
+  enum Ty : uint8_t { I, R, B } ty;
+  bool is_const = false;
+  uint64_t bits = 0;   // constant payload: i64, f64 bits, or 0/1
+  int op = -1;         // gmlrt_sop, or -1 for an input register
+  int input = -1;      // 0 face, 1 u, 2 v
+  ExprP a, b, c;
+  // linearisation state
+  int uses = 0;
+  int reg = -1;
+  bool emitted = false;
+  int64_t iv() const { return (int64_t)bits; }
+  double rv() const { return vm_as_f64(bits); }
+};
+
+struct AClosure;
+struct AVal;
+using AVec = std::vector<AVal>;
+struct AVal {
+  enum K : uint8_t { Scalar, Point, Closure, Array, Other } k = Other;
+  ExprP s;
+  ExprP p[3];
+  std::shared_ptr<const AClosure> clo;
+  std::shared_ptr<const AVec> arr;  // storage order of the reference: reversed
+  gml::ValuePtr other;
+};
+using AMap = std::unordered_map<std::string, AVal>;
+struct AClosure {
+  std::shared_ptr<const AMap> asnap;
+  std::shared_ptr<const gml::EnvMap> base;  // concrete captured environment
+  std::shared_ptr<const gml::AstList> ast;
+};
+using AStack = std::vector<AVal>;
+
+struct Compiler {
+  // hash-consing of expressions so that both arms of an `if` share common work
+  std::map<std::tuple<int, int, const Expr*, const Expr*, const Expr*>, ExprP> cse;
+  std::map<std::pair<int, uint64_t>, ExprP> const_cse;
+  ExprP inputs[3];
+  long steps = 0;
+
+  Compiler() {
+    for (int i = 0; i < 3; i++) {
+      inputs[i] = std::make_shared<Expr>();
+      inputs[i]->ty = i == 0 ? Expr::I : Expr::R;
+      inputs[i]->input = i;
+    }
+  }
+
+  ExprP konst(Expr::Ty ty, uint64_t bits) {
+    auto key = std::make_pair((int)ty, bits);
+    auto it = const_cse.find(key);
+    if (it != const_cse.end()) return it->second;
+    auto e = std::make_shared<Expr>();
+    e->ty = ty; e->is_const = true; e->bits = bits;
+    const_cse[key] = e;
+    return e;
+  }
+  ExprP ki(int64_t v) { return konst(Expr::I, (uint64_t)v); }
+  ExprP kr(double v) { return konst(Expr::R, vm_from_f64(v)); }
+  ExprP kb(bool v) { return konst(Expr::B, v ? 1 : 0); }
+
+  ExprP node(int op, Expr::Ty ty, ExprP a, ExprP b = nullptr, ExprP c = nullptr) {
+    auto key = std::make_tuple(op, (int)ty, (const Expr*)a.get(), (const Expr*)b.get(), (const Expr*)c.get());
+    auto it = cse.find(key);
+    if (it != cse.end()) return it->second;
+    auto e = std::make_shared<Expr>();
+    e->ty = ty; e->op = op; e->a = a; e->b = b; e->c = c;
+    cse[key] = e;
+    return e;
+  }
+
+  // ---- typed accessors
+  static const ExprP& want(const AVal& v, Expr::Ty ty) {
+    if (v.k != AVal::Scalar || v.s->ty != ty) throw gml::GmlError("WrongTypeRef");
+    return v.s;
+  }
+  static AVal scalar(ExprP e) { AVal v; v.k = AVal::Scalar; v.s = std::move(e); return v; }
+
+  AVal from_concrete(const gml::ValuePtr& v) {
+    AVal r;
+    switch (v->kind) {
+      case gml::Value::Integer: return scalar(ki(v->i));
+      case gml::Value::Real: return scalar(kr(v->r));
+      case gml::Value::Boolean: return scalar(kb(v->b));
+      case gml::Value::Point:
+        r.k = AVal::Point;
+        for (int i = 0; i < 3; i++) r.p[i] = kr(v->p[(size_t)i]);
+        return r;
+      case gml::Value::Closure: {
+        auto c = std::make_shared<AClosure>();
+        c->asnap = empty_amap();
+        c->base = v->env;
+        c->ast = v->ast;
+        r.k = AVal::Closure; r.clo = c;
+        return r;
+      }
+      case gml::Value::Array: {
+        auto vec = std::make_shared<AVec>();
+        for (auto& e : v->arr) vec->push_back(from_concrete(e));
+        r.k = AVal::Array; r.arr = vec;
+        return r;
+      }
+      default:
+        r.k = AVal::Other; r.other = v;
+        return r;
+    }
+  }
+
+  static std::shared_ptr<const AMap> empty_amap() {
+    static const std::shared_ptr<const AMap> e = std::make_shared<AMap>();
+    return e;
+  }
+
+  // ---- environment with the reference's snapshot rule (evaluator.rs:87-100):
+  // entries of the older snapshot win over the current bindings.
+  struct AEnv {
+    std::shared_ptr<const AMap> asnap;
+    std::shared_ptr<const gml::EnvMap> base;
+    AMap current;
+  };
+  bool lookup(const AEnv& e, const std::string& k, AVal* out) {
+    auto ic = e.current.find(k);
+    if (ic != e.current.end()) { *out = ic->second; return true; }
+    auto is = e.asnap->find(k);
+    if (is != e.asnap->end()) { *out = is->second; return true; }
+    auto ib = e.base->find(k);
+    if (ib != e.base->end()) { *out = from_concrete(ib->second); return true; }
+    return false;
+  }
+  static std::shared_ptr<const AMap> snapshot(const AEnv& e) {
+    if (e.current.empty()) return e.asnap;
+    auto m = std::make_shared<AMap>(*e.asnap);
+    for (auto& kv : e.current)
+      if (!e.asnap->count(kv.first) && !e.base->count(kv.first)) (*m)[kv.first] = kv.second;
+    return m;
+  }
+
+  // ---- scalar ops with constant folding through the evaluator's own arithmetic
+  ExprP binop_i(int op, const ExprP& a, const ExprP& b) {
+    if (a->is_const && b->is_const) {
+      const int64_t x = a->iv(), y = b->iv();
+      switch (op) {
+        case GMLRT_SOP_ADDI: return ki((int64_t)((uint64_t)x + (uint64_t)y));
+        case GMLRT_SOP_SUBI: return ki((int64_t)((uint64_t)x - (uint64_t)y));
+        case GMLRT_SOP_MULI: return ki((int64_t)((uint64_t)x * (uint64_t)y));
+        case GMLRT_SOP_DIVI: return ki(gml::divi(x, y));
+        case GMLRT_SOP_MODI: return ki(gml::modi(x, y));
+        case GMLRT_SOP_EQI: return kb(x == y);
+        case GMLRT_SOP_LESSI: return kb(x < y);
+      }
+    }
+    const bool pred = op == GMLRT_SOP_EQI || op == GMLRT_SOP_LESSI;
+    return node(op, pred ? Expr::B : Expr::I, a, b);
+  }
+  ExprP binop_r(int op, const ExprP& a, const ExprP& b) {
+    if (a->is_const && b->is_const) {
+      const double x = a->rv(), y = b->rv();
+      switch (op) {
+        case GMLRT_SOP_ADDF: return kr(x + y);
+        case GMLRT_SOP_SUBF: return kr(x - y);
+        case GMLRT_SOP_MULF: return kr(x * y);
+        case GMLRT_SOP_DIVF: return kr(x / y);
+        case GMLRT_SOP_EQF: return kb(x == y);
+        case GMLRT_SOP_LESSF: return kb(x < y);
+      }
+    }
+    const bool pred = op == GMLRT_SOP_EQF || op == GMLRT_SOP_LESSF;
+    return node(op, pred ? Expr::B : Expr::R, a, b);
+  }
+  ExprP unop_r(int op, const ExprP& a) {
+    if (a->is_const) {
+      const double x = a->rv();
+      switch (op) {
+        case GMLRT_SOP_SQRT: return kr(std::sqrt(x));
+        case GMLRT_SOP_FRAC: return kr(gml::gml_frac(x));
+        case GMLRT_SOP_CLAMPF: return kr(gml::gml_clampf(x));
+        case GMLRT_SOP_SIN: return kr(gml::gml_sin(x));
+        case GMLRT_SOP_COS: return kr(gml::gml_cos(x));
+        case GMLRT_SOP_ASIN: return kr(gml::gml_asin(x));
+        case GMLRT_SOP_ACOS: return kr(gml::gml_acos(x));
+      }
+    }
+    return node(op, Expr::R, a);
+  }
+
+  ExprP select_expr(const ExprP& pred, const ExprP& x, const ExprP& y) {
+    if (x.get() == y.get()) return x;
+    if (x->ty != y->ty) throw UnsupportedSurface("`if` arms leave values of different types");
+    return node(GMLRT_SOP_SELECT, x->ty, pred, x, y);
+  }
+  AVal select_val(const ExprP& pred, const AVal& x, const AVal& y) {
+    if (x.k != y.k) throw UnsupportedSurface("`if` arms leave values of different kinds");
+    switch (x.k) {
+      case AVal::Scalar: return scalar(select_expr(pred, x.s, y.s));
+      case AVal::Point: {
+        AVal r; r.k = AVal::Point;
+        for (int i = 0; i < 3; i++) r.p[i] = select_expr(pred, x.p[i], y.p[i]);
+        return r;
+      }
+      case AVal::Closure:
+        if (x.clo.get() == y.clo.get()) return x;
+        throw UnsupportedSurface("`if` arms leave different closures");
+      case AVal::Array:
+        if (x.arr.get() == y.arr.get()) return x;
+        if (x.arr->size() == y.arr->size()) {
+          auto vec = std::make_shared<AVec>();
+          for (size_t i = 0; i < x.arr->size(); i++) vec->push_back(select_val(pred, (*x.arr)[i], (*y.arr)[i]));
+          AVal r; r.k = AVal::Array; r.arr = vec;
+          return r;
+        }
+        throw UnsupportedSurface("`if` arms leave arrays of different length");
+      default:
+        if (x.other.get() == y.other.get()) return x;
+        throw UnsupportedSurface("`if` arms leave different non-scalar values");
+    }
+  }
+
+  static AVal pop(AStack& s) {
+    if (s.empty()) throw gml::GmlError("EmptyStack");
+    AVal v = std::move(s.back());
+    s.pop_back();
+    return v;
+  }
+
+  void call(const AVal& c, AStack& stack) {
+    if (c.k != AVal::Closure) throw gml::GmlError("WrongType");
+    AEnv e{c.clo->asnap, c.clo->base, {}};
+    eval(e, stack, *c.clo->ast);
+  }
+
+  void eval_op(gml::Op op, AStack& st) {
+    using gml::Op;
+    auto bin_i = [&](int sop) { AVal b = pop(st), a = pop(st); st.push_back(scalar(binop_i(sop, want(a, Expr::I), want(b, Expr::I)))); };
+    auto bin_r = [&](int sop) { AVal b = pop(st), a = pop(st); st.push_back(scalar(binop_r(sop, want(a, Expr::R), want(b, Expr::R)))); };
+    auto un_r = [&](int sop) { AVal a = pop(st); st.push_back(scalar(unop_r(sop, want(a, Expr::R)))); };
+    switch (op) {
+      case Op::Addi: bin_i(GMLRT_SOP_ADDI); break;
+      case Op::Subi: bin_i(GMLRT_SOP_SUBI); break;
+      case Op::Muli: bin_i(GMLRT_SOP_MULI); break;
+      case Op::Divi: bin_i(GMLRT_SOP_DIVI); break;
+      case Op::Modi: bin_i(GMLRT_SOP_MODI); break;
+      case Op::Eqi: bin_i(GMLRT_SOP_EQI); break;
+      case Op::Lessi: bin_i(GMLRT_SOP_LESSI); break;
+      case Op::Addf: bin_r(GMLRT_SOP_ADDF); break;
+      case Op::Subf: bin_r(GMLRT_SOP_SUBF); break;
+      case Op::Mulf: bin_r(GMLRT_SOP_MULF); break;
+      case Op::Divf: bin_r(GMLRT_SOP_DIVF); break;
+      case Op::Eqf: bin_r(GMLRT_SOP_EQF); break;
+      case Op::Lessf: bin_r(GMLRT_SOP_LESSF); break;
+      case Op::Sqrt: un_r(GMLRT_SOP_SQRT); break;
+      case Op::Frac: un_r(GMLRT_SOP_FRAC); break;
+      case Op::Clampf: un_r(GMLRT_SOP_CLAMPF); break;
+      case Op::Sin: un_r(GMLRT_SOP_SIN); break;
+      case Op::Cos: un_r(GMLRT_SOP_COS); break;
+      case Op::Asin: un_r(GMLRT_SOP_ASIN); break;
+      case Op::Acos: un_r(GMLRT_SOP_ACOS); break;
+      case Op::Negi: { AVal a = pop(st); st.push_back(scalar(want(a, Expr::I))); break; }  // no-op in the reference
+      case Op::Negf: { AVal a = pop(st); st.push_back(scalar(want(a, Expr::R))); break; }
+      case Op::Real: {
+        AVal a = pop(st);
+        const ExprP& e = want(a, Expr::I);
+        st.push_back(scalar(e->is_const ? kr((double)e->iv()) : node(GMLRT_SOP_REAL, Expr::R, e)));
+        break;
+      }
+      case Op::Floor: {
+        AVal a = pop(st);
+        const ExprP& e = want(a, Expr::R);
+        st.push_back(scalar(e->is_const ? ki(gml::gml_floor(e->rv())) : node(GMLRT_SOP_FLOOR, Expr::I, e)));
+        break;
+      }
+      case Op::Point: {
+        AVal z = pop(st), y = pop(st), x = pop(st);
+        AVal r; r.k = AVal::Point;
+        r.p[0] = want(x, Expr::R); r.p[1] = want(y, Expr::R); r.p[2] = want(z, Expr::R);
+        st.push_back(r);
+        break;
+      }
+      case Op::Getx: case Op::Gety: case Op::Getz: {
+        AVal p = pop(st);
+        if (p.k != AVal::Point) throw gml::GmlError("WrongTypeRef");
+        st.push_back(scalar(p.p[op == Op::Getx ? 0 : op == Op::Gety ? 1 : 2]));
+        break;
+      }
+      case Op::Length: {
+        AVal a = pop(st);
+        if (a.k != AVal::Array) throw gml::GmlError("WrongTypeRef");
+        st.push_back(scalar(ki((int64_t)a.arr->size())));
+        break;
+      }
+      case Op::Get: {
+        AVal i = pop(st), a = pop(st);
+        const ExprP& ie = want(i, Expr::I);
+        if (a.k != AVal::Array) throw gml::GmlError("WrongTypeRef");
+        const int64_t len = (int64_t)a.arr->size();
+        if (ie->is_const) {
+          const int64_t iv = ie->iv();
+          if (iv < 0 || iv >= len) throw gml::GmlError("ArrayOutOfBounds");
+          st.push_back((*a.arr)[(size_t)(len - iv - 1)]);
+        } else {
+          // data-dependent index: a chain of selects over the elements.  An index
+          // outside [0,len) aborts the reference; here it yields element 0.
+          if (len == 0) throw gml::GmlError("ArrayOutOfBounds");
+          if (len > 256) throw UnsupportedSurface("data-dependent `get` on an array longer than 256");
+          AVal r = (*a.arr)[(size_t)(len - 1)];
+          for (int64_t k = 1; k < len; k++)
+            r = select_val(binop_i(GMLRT_SOP_EQI, ie, ki(k)), (*a.arr)[(size_t)(len - k - 1)], r);
+          st.push_back(r);
+        }
+        break;
+      }
+      case Op::Apply: { AVal c = pop(st); call(c, st); break; }
+      case Op::If: {
+        AVal c2 = pop(st), c1 = pop(st), pred = pop(st);
+        const ExprP& pe = want(pred, Expr::B);
+        if (pe->is_const) {
+          call(pe->bits ? c1 : c2, st);
+        } else {
+          AStack s1 = st, s2 = st;
+          call(c1, s1);
+          call(c2, s2);
+          if (s1.size() != s2.size()) throw UnsupportedSurface("`if` arms leave stacks of different depth");
+          st.clear();
+          for (size_t k = 0; k < s1.size(); k++) st.push_back(select_val(pe, s1[k], s2[k]));
+        }
+        break;
+      }
+      default:
+        throw UnsupportedSurface(std::string("operator `") + gml::op_name(op) + "` inside a surface function");
+    }
+  }
+
+  void eval(AEnv& env, AStack& st, const gml::AstList& ast) {
+    for (const gml::AstNode& item : ast) {
+      if (++steps > 2000000) throw UnsupportedSurface("surface function does not terminate under symbolic evaluation");
+      switch (item.kind) {
+        case gml::AstNode::Function: {
+          auto c = std::make_shared<AClosure>();
+          c->asnap = snapshot(env);
+          c->base = env.base;
+          c->ast = item.children;
+          AVal v; v.k = AVal::Closure; v.clo = c;
+          st.push_back(v);
+          break;
+        }
+        case gml::AstNode::Array: {
+          AStack local;
+          eval(env, local, *item.children);
+          auto vec = std::make_shared<AVec>(local.rbegin(), local.rend());
+          AVal v; v.k = AVal::Array; v.arr = vec;
+          st.push_back(v);
+          break;
+        }
+        case gml::AstNode::Leaf: {
+          const gml::Token& t = item.tok;
+          switch (t.kind) {
+            case gml::Token::Integer: st.push_back(scalar(ki(t.i))); break;
+            case gml::Token::Real: st.push_back(scalar(kr(t.r))); break;
+            case gml::Token::Boolean: st.push_back(scalar(kb(t.b))); break;
+            case gml::Token::Str: {
+              auto sv = std::make_shared<gml::Value>();
+              sv->kind = gml::Value::String; sv->s = t.s;
+              AVal v; v.k = AVal::Other; v.other = sv;
+              st.push_back(v);
+              break;
+            }
+            case gml::Token::Binder: env.current[t.s] = pop(st); break;
+            case gml::Token::Identifier: {
+              AVal v;
+              if (!lookup(env, t.s, &v)) throw gml::GmlError("environment missing identifier: " + t.s);
+              st.push_back(v);
+              break;
+            }
+            case gml::Token::Operator: eval_op(t.op, st); break;
+            default: throw gml::GmlError("InvalidAst");
+          }
+          break;
+        }
+      }
+    }
+  }
+
+  // ---- linearisation
+  struct Emit {
+    std::vector<uint64_t> code;
+    std::vector<uint64_t> consts;
+    std::map<uint64_t, uint32_t> const_idx;
+    std::vector<int> free_regs;
+    int next_reg = 3;
+  };
+
+  static void count_uses(const ExprP& e) {
+    if (!e || e->is_const) return;
+    if (e->uses++ > 0) return;
+    count_uses(e->a); count_uses(e->b); count_uses(e->c);
+  }
+  static uint32_t operand(Emit& em, const ExprP& e) {
+    if (!e) return 0;
+    if (e->is_const) {
+      auto it = em.const_idx.find(e->bits);
+      uint32_t idx;
+      if (it == em.const_idx.end()) {
+        idx = (uint32_t)em.consts.size();
+        if (idx >= 0x8000u) throw UnsupportedSurface("surface function needs more than 32768 constants");
+        em.consts.push_back(e->bits);
+        em.const_idx[e->bits] = idx;
+      } else {
+        idx = it->second;
+      }
+      return 0x8000u | idx;
+    }
+    return (uint32_t)e->reg;
+  }
+  static void release(Emit& em, const ExprP& e) {
+    if (!e || e->is_const || e->input >= 0) return;
+    if (--e->uses == 0) em.free_regs.push_back(e->reg);
+  }
+  static void emit_expr(Emit& em, const ExprP& e) {
+    if (!e || e->is_const || e->input >= 0 || e->emitted) return;
+    emit_expr(em, e->a); emit_expr(em, e->b); emit_expr(em, e->c);
+    const uint32_t oa = operand(em, e->a), ob = operand(em, e->b), oc = operand(em, e->c);
+    // an operand dies here once per reference to it
+    release(em, e->a); release(em, e->b); release(em, e->c);
+    int reg;
+    if (!em.free_regs.empty()) { reg = em.free_regs.back(); em.free_regs.pop_back(); }
+    else reg = em.next_reg++;
+    if (reg >= GMLRT_SURF_MAX_REGS) throw UnsupportedSurface("surface function needs more than 64 live values");
+    e->reg = reg;
+    e->emitted = true;
+    em.code.push_back((uint64_t)(uint32_t)e->op | ((uint64_t)(uint32_t)reg << 8) | ((uint64_t)oa << 16) |
+                      ((uint64_t)ob << 32) | ((uint64_t)oc << 48));
+  }
+};
+
+}  // namespace
+
+SurfaceProgram compile_surface(const gml::Value& closure) {
+  if (closure.kind != gml::Value::Closure) throw gml::GmlError("WrongTypeRef");
+  Compiler c;
+  for (int i = 0; i < 3; i++) c.inputs[i]->reg = i;
+  Compiler::AEnv env{Compiler::empty_amap(), closure.env, {}};
+  AStack st;
+  for (int i = 0; i < 3; i++) st.push_back(Compiler::scalar(c.inputs[i]));
+  c.eval(env, st, *closure.ast);
+  // pop n, ks, kd, colour (evaluator.rs:784-791)
+  AVal n = Compiler::pop(st), ks = Compiler::pop(st), kd = Compiler::pop(st), col = Compiler::pop(st);
+  ExprP out[6];
+  if (col.k != AVal::Point) throw gml::GmlError("wrong type");
+  for (int i = 0; i < 3; i++) out[i] = col.p[i];
+  out[3] = Compiler::want(kd, Expr::R);
+  out[4] = Compiler::want(ks, Expr::R);
+  out[5] = Compiler::want(n, Expr::R);
+
+  SurfaceProgram sp;
+  bool all_const = true;
+  for (auto& e : out) all_const = all_const && e->is_const;
+  if (all_const) {
+    sp.constant = true;
+    for (auto& e : out) sp.consts.push_back(e->bits);
+    return sp;
+  }
+  Compiler::Emit em;
+  // each OUT operand counts as a use so that its register stays live until the OUT
+  for (auto& e : out) Compiler::count_uses(e);
+  for (auto& e : out) Compiler::emit_expr(em, e);
+  for (int g = 0; g < 2; g++) {
+    const uint32_t oa = Compiler::operand(em, out[g * 3]), ob = Compiler::operand(em, out[g * 3 + 1]),
+                   oc = Compiler::operand(em, out[g * 3 + 2]);
+    em.code.push_back((uint64_t)GMLRT_SOP_OUT | ((uint64_t)(g * 3) << 8) | ((uint64_t)oa << 16) | ((uint64_t)ob << 32) |
+                      ((uint64_t)oc << 48));
+  }
+  em.code.push_back(GMLRT_SOP_END);
+  sp.code = std::move(em.code);
+  sp.consts = std::move(em.consts);
+  return sp;
+}
+
+void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+  if (p.constant) {
+    for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
+    return;
+  }
+  surface_vm(p.code.data(), p.consts.data(), face, u, v, out);
+}
+
+// ============================================================== flattening
+namespace {
+
+struct Flattener : gml::TreeVisitor {
+  std::vector<gmlrt_leaf> leaves;
+  std::vector<uint32_t> nodes;
+  std::vector<uint64_t> code;
+  std::vector<uint64_t> consts;
+  std::map<const gml::Value*, std::pair<uint32_t, uint32_t>> by_closure;
+  std::map<std::vector<uint64_t>, uint32_t> by_code, by_consts;
+  // operand stack of the postfix program: (is_leaf, worst-case event count)
+  std::vector<std::pair<bool, uint64_t>> ostack;
+  uint64_t sp = 0, max_events = 0;
+  size_t max_stack = 0;
+
+  void leaf(gml::PrimType prim, const gml::ValuePtr& surface, const gml::Transform& t) override {
+    gmlrt_leaf L;
+    std::memset(&L, 0, sizeof(L));
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) {
+        L.inv_m[i * 4 + j] = t.inv_m.m[i][j];
+        L.m[i * 4 + j] = t.m.m[i][j];
+      }
+    L.type = (uint32_t)prim;
+    auto it = by_closure.find(surface.get());
+    if (it == by_closure.end()) {
+      SurfaceProgram sp = compile_surface(*surface);
+      uint32_t code_off = GMLRT_SURF_CONST;
+      if (!sp.constant) {
+        auto ic = by_code.find(sp.code);
+        if (ic == by_code.end()) {
+          code_off = (uint32_t)code.size();
+          code.insert(code.end(), sp.code.begin(), sp.code.end());
+          by_code[sp.code] = code_off;
+        } else {
+          code_off = ic->second;
+        }
+      }
+      uint32_t const_off;
+      auto ik = by_consts.find(sp.consts);
+      if (ik == by_consts.end()) {
+        const_off = (uint32_t)consts.size();
+        consts.insert(consts.end(), sp.consts.begin(), sp.consts.end());
+        by_consts[sp.consts] = const_off;
+      } else {
+        const_off = ik->second;
+      }
+      it = by_closure.emplace(surface.get(), std::make_pair(code_off, const_off)).first;
+    }
+    L.surf_code = it->second.first;
+    L.surf_const = it->second.second;
+    if (leaves.size() >= (1u << 20)) throw gml::GmlError("scene has more than 2^20 leaves");
+    nodes.push_back(GMLRT_NODE_LEAF(leaves.size()));
+    leaves.push_back(L);
+    ostack.emplace_back(true, 2);
+    sp += 2;
+    max_events = std::max(max_events, sp);
+    max_stack = std::max(max_stack, ostack.size());
+  }
+  void op(gml::Rule rule) override {
+    auto b = ostack.back(); ostack.pop_back();
+    auto a = ostack.back(); ostack.pop_back();
+    nodes.push_back(GMLRT_NODE_OP((uint32_t)rule, a.first, b.first));
+    // the merge writes its output above both operands before moving it down
+    max_events = std::max(max_events, sp + a.second + b.second);
+    ostack.emplace_back(false, a.second + b.second);
+  }
+};
+
+template <class T>
+void append(std::vector<uint8_t>& blob, uint64_t* off, const std::vector<T>& v) {
+  while (blob.size() % 16) blob.push_back(0);
+  *off = blob.size();
+  const uint8_t* p = (const uint8_t*)v.data();
+  blob.insert(blob.end(), p, p + v.size() * sizeof(T));
+}
+
+}  // namespace
+
+std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc) {
+  Flattener f;
+  gml::walk_postfix(rc.scene, f);
+  std::vector<gmlrt_light> lights;
+  for (auto& l : rc.lights) {
+    gmlrt_light g;
+    std::memset(&g, 0, sizeof(g));
+    g.kind = (uint32_t)l->kind;
+    for (int i = 0; i < 3; i++) { g.dir[i] = l->dir[(size_t)i]; g.pos[i] = l->pos[(size_t)i]; g.color[i] = l->color[(size_t)i]; }
+    g.coscutoff = l->coscutoff;
+    g.exp = l->exp;
+    lights.push_back(g);
+  }
+  gmlrt_blob_header h;
+  std::memset(&h, 0, sizeof(h));
+  h.magic = GMLRT_BLOB_MAGIC;
+  h.version = GMLRT_BLOB_VERSION;
+  h.n_leaves = (uint32_t)f.leaves.size();
+  h.n_nodes = (uint32_t)f.nodes.size();
+  h.n_lights = (uint32_t)lights.size();
+  h.n_code_words = (uint32_t)f.code.size();
+  h.n_consts = (uint32_t)f.consts.size();
+  h.max_stack = (uint32_t)f.max_stack;
+  if (f.max_events > 0xFFFFFFFFull) throw gml::GmlError("scene too large");
+  h.max_events = (uint32_t)f.max_events;
+  std::vector<uint8_t> blob(sizeof(h), 0);
+  append(blob, &h.off_leaves, f.leaves);
+  append(blob, &h.off_nodes, f.nodes);
+  append(blob, &h.off_lights, lights);
+  append(blob, &h.off_code, f.code);
+  append(blob, &h.off_consts, f.consts);
+  while (blob.size() % 16) blob.push_back(0);
+  h.total_bytes = blob.size();
+  std::memcpy(blob.data(), &h, sizeof(h));
+  return blob;
+}
+
+// ============================================================== validation
+std::string validate_blob(const void* blob, size_t bytes) {
+  if (!blob || bytes < sizeof(gmlrt_blob_header)) return "blob shorter than its header";
+  gmlrt_blob_header h;
+  std::memcpy(&h, blob, sizeof(h));
+  if (h.magic != GMLRT_BLOB_MAGIC) return "bad magic";
+  if (h.version != GMLRT_BLOB_VERSION) return "unsupported blob version";
+  if (h.total_bytes != bytes) return "total_bytes does not match the buffer size";
+  if (h.n_leaves == 0 || h.n_leaves > (1u << 20)) return "leaf count out of range";
+  if (h.n_nodes != 2 * h.n_leaves - 1) return "node count is not 2*leaves-1";
+  auto section_ok = [&](uint64_t off, uint64_t count, uint64_t elem) {
+    return off % 8 == 0 && off >= sizeof(h) && off <= bytes && count * elem <= bytes - off;
+  };
+  if (!section_ok(h.off_leaves, h.n_leaves, sizeof(gmlrt_leaf))) return "leaf section out of bounds";
+  if (!section_ok(h.off_nodes, h.n_nodes, 4)) return "node section out of bounds";
+  if (!section_ok(h.off_lights, h.n_lights, sizeof(gmlrt_light))) return "light section out of bounds";
+  if (!section_ok(h.off_code, h.n_code_words, 8)) return "code section out of bounds";
+  if (!section_ok(h.off_consts, h.n_consts, 8)) return "constant section out of bounds";
+  const uint8_t* base = (const uint8_t*)blob;
+  const gmlrt_leaf* leaves = (const gmlrt_leaf*)(base + h.off_leaves);
+  const uint32_t* nodes = (const uint32_t*)(base + h.off_nodes);
+  const uint64_t* code = (const uint64_t*)(base + h.off_code);
+  const gmlrt_light* lights = (const gmlrt_light*)(base + h.off_lights);
+  // postfix program: every leaf used exactly once and in order, stack discipline,
+  // operand-kind flags and the two capacity fields must be what the traversal assumes
+  std::vector<std::pair<bool, uint64_t>> st;
+  uint64_t sp = 0, max_events = 0;
+  size_t max_stack = 0;
+  uint32_t next_leaf = 0;
+  for (uint32_t i = 0; i < h.n_nodes; i++) {
+    const uint32_t w = nodes[i];
+    const uint32_t kind = w >> 30;
+    if (kind == 0) {
+      if ((w & 0x3FFFFFFFu) != next_leaf) return "leaves must appear in index order";
+      next_leaf++;
+      st.emplace_back(true, 2);
+      sp += 2;
+      max_events = std::max(max_events, sp);
+      max_stack = std::max(max_stack, st.size());
+    } else if (kind == 1) {
+      if ((w & 3u) > 2u || (w & 0x3FFFFFF0u) != 0) return "bad operator word";
+      if (st.size() < 2) return "postfix program underflows its stack";
+      auto b = st.back(); st.pop_back();
+      auto a = st.back(); st.pop_back();
+      if (((w >> 2) & 1u) != (a.first ? 1u : 0u) || ((w >> 3) & 1u) != (b.first ? 1u : 0u))
+        return "operator leaf-operand flags do not match the tree";
+      max_events = std::max(max_events, sp + a.second + b.second);
+      st.emplace_back(false, a.second + b.second);
+    } else {
+      return "bad node word";
+    }
+  }
+  if (st.size() != 1 || next_leaf != h.n_leaves) return "postfix program does not reduce to one root";
+  if (h.max_stack < max_stack) return "max_stack too small";
+  if (h.max_events < max_events) return "max_events too small";
+  for (uint32_t i = 0; i < h.n_lights; i++)
+    if (lights[i].kind > GMLRT_LIGHT_SPOT) return "bad light kind";
+  for (uint32_t i = 0; i < h.n_leaves; i++) {
+    const gmlrt_leaf& L = leaves[i];
+    if (L.type > GMLRT_PLANE) return "bad primitive type";
+    if (L.surf_code == GMLRT_SURF_CONST) {
+      if ((uint64_t)L.surf_const + 6 > h.n_consts) return "constant surface out of bounds";
+      continue;
+    }
+    if (L.surf_code >= h.n_code_words) return "surface code offset out of bounds";
+    bool ended = false;
+    for (uint32_t pc = L.surf_code; pc < h.n_code_words; pc++) {
+      const uint64_t w = code[pc];
+      const uint32_t op = (uint32_t)(w & 0xFF);
+      if (op >= GMLRT_SOP__COUNT) return "bad surface opcode";
+      if (op == GMLRT_SOP_END) { ended = true; break; }
+      const uint32_t dst = (uint32_t)((w >> 8) & 0xFF);
+      if (op == GMLRT_SOP_OUT ? (dst != 0 && dst != 3) : dst >= GMLRT_SURF_MAX_REGS) return "bad surface destination";
+      for (int k = 0; k < 3; k++) {
+        const uint32_t o = (uint32_t)((w >> (16 + 16 * k)) & 0xFFFF);
+        if (o & 0x8000u) {
+          if ((uint64_t)L.surf_const + (o & 0x7FFFu) >= h.n_consts) return "surface constant out of bounds";
+        } else if (o >= GMLRT_SURF_MAX_REGS) {
+          return "surface register out of bounds";
+        }
+      }
+    }
+    if (!ended) return "surface code runs off the end of the section";
+  }
+  return "";
+}
+
+}  // namespace gmlrt

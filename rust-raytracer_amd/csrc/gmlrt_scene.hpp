@@ -1,0 +1,42 @@
+// Host-side scene flattening: turns the operands of one `render` call
+// (gml::RenderCall) into the contiguous blob declared in include/gmlrt.h.
+//   - every leaf primitive with its finished (m, inv_m) pair
+//   - the CSG tree as a postfix program
+//   - the lights with their constructor-derived fields
+//   - every surface closure compiled to straight-line bytecode
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/gmlrt.h"
+#include "gml_front.hpp"
+
+namespace gmlrt {
+
+struct UnsupportedSurface : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// Result of compiling one surface closure (evaluator.rs:776-792 protocol).
+struct SurfaceProgram {
+  bool constant = false;           // body never reads face/u/v: consts[0..6) = r g b kd ks n
+  std::vector<uint64_t> code;      // bytecode words, ends with GMLRT_SOP_END
+  std::vector<uint64_t> consts;    // 8-byte constants (f64 or i64 bit patterns)
+};
+
+// Symbolically executes the closure with (face,u,v) unknown.  Both arms of a
+// data-dependent `if` are evaluated and joined with SELECT, so the result has no
+// control flow.  Throws UnsupportedSurface / gml::GmlError.
+SurfaceProgram compile_surface(const gml::Value& closure);
+
+// Reference interpreter of the bytecode on the host (used by unit tests to check
+// the compiler against the tree-walking evaluator; the device has its own copy).
+void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+
+// Flattens one render call.  Throws UnsupportedSurface / gml::GmlError.
+std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc);
+
+// Structural validation of a blob received over the C ABI.  Returns "" if fine.
+std::string validate_blob(const void* blob, size_t bytes);
+
+}  // namespace gmlrt

@@ -1,0 +1,106 @@
+// Interpreter of the surface bytecode declared in include/gmlrt.h, written once
+// and compiled for both sides: the device kernel runs it per hit, the host runs
+// it in unit tests to check the surface compiler against the GML evaluator.
+// Scalar semantics follow /root/reference/src/evaluator.rs (line numbers per op
+// in include/gmlrt.h).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/gmlrt.h"
+
+#ifdef __HIPCC__
+#define GMLRT_HD __host__ __device__ inline
+#else
+#define GMLRT_HD inline
+#endif
+
+#define GMLRT_SURF_MAX_REGS 64
+
+namespace gmlrt {
+
+GMLRT_HD double vm_as_f64(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+GMLRT_HD uint64_t vm_from_f64(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+// `f.floor() as i64` (evaluator.rs:388-391): saturating, NaN -> 0
+GMLRT_HD int64_t vm_floor_i64(double x) {
+  double f = floor(x);
+  if (!(f == f)) return 0;
+  if (f >= 9223372036854775808.0) return INT64_MAX;
+  if (f <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)f;
+}
+// evaluator.rs:212-218.  The reference panics on a zero divisor (and on
+// i64::MIN / -1); the bytecode defines both as 0 so that a SELECT may discard them.
+GMLRT_HD int64_t vm_divi(int64_t a, int64_t b) {
+  if (b == 0 || (a == INT64_MIN && b == -1)) return 0;
+  return a / b;
+}
+GMLRT_HD int64_t vm_modi(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b * (uint64_t)vm_divi(a, b)); }
+GMLRT_HD double vm_to_radians(double d) { return d * (3.14159265358979323846 / 180.0); }
+GMLRT_HD double vm_to_degrees(double r) { return r * (180.0 / 3.14159265358979323846); }
+GMLRT_HD double vm_sin(double x) { double r = sin(vm_to_radians(x)); return fabs(r) < 1e-15 ? 0.0 : r; }
+GMLRT_HD double vm_cos(double x) { double r = cos(vm_to_radians(x)); return fabs(r) < 1e-15 ? 0.0 : r; }
+GMLRT_HD double vm_frac(double x) { return x - trunc(x); }
+GMLRT_HD double vm_clampf(double x) { return fmin(fmax(x, 0.0), 1.0); }
+
+// Runs `code` until GMLRT_SOP_END.  consts points at this surface's first constant.
+GMLRT_HD void surface_vm(const uint64_t* code, const uint64_t* consts, int64_t face, double u, double v,
+                         double out[6]) {
+  uint64_t r[GMLRT_SURF_MAX_REGS];
+  r[0] = (uint64_t)face;
+  r[1] = vm_from_f64(u);
+  r[2] = vm_from_f64(v);
+#define OPND(x) (((x) & 0x8000u) ? consts[(x) & 0x7FFFu] : r[(x) & (GMLRT_SURF_MAX_REGS - 1)])
+  for (uint32_t pc = 0;; pc++) {
+    const uint64_t w = code[pc];
+    const uint32_t op = (uint32_t)(w & 0xFF);
+    if (op == GMLRT_SOP_END) break;
+    const uint32_t dst = (uint32_t)((w >> 8) & 0xFF);
+    const uint32_t oa = (uint32_t)((w >> 16) & 0xFFFF), ob = (uint32_t)((w >> 32) & 0xFFFF),
+                   oc = (uint32_t)((w >> 48) & 0xFFFF);
+    const uint64_t a = OPND(oa), b = OPND(ob);
+    const double fa = vm_as_f64(a), fb = vm_as_f64(b);
+    const int64_t ia = (int64_t)a, ib = (int64_t)b;
+    uint64_t res = 0;
+    switch (op) {
+      case GMLRT_SOP_MOV: res = a; break;
+      case GMLRT_SOP_ADDI: res = a + b; break;
+      case GMLRT_SOP_SUBI: res = a - b; break;
+      case GMLRT_SOP_MULI: res = a * b; break;
+      case GMLRT_SOP_DIVI: res = (uint64_t)vm_divi(ia, ib); break;
+      case GMLRT_SOP_MODI: res = (uint64_t)vm_modi(ia, ib); break;
+      case GMLRT_SOP_EQI: res = ia == ib; break;
+      case GMLRT_SOP_LESSI: res = ia < ib; break;
+      case GMLRT_SOP_REAL: res = vm_from_f64((double)ia); break;
+      case GMLRT_SOP_FLOOR: res = (uint64_t)vm_floor_i64(fa); break;
+      case GMLRT_SOP_ADDF: res = vm_from_f64(fa + fb); break;
+      case GMLRT_SOP_SUBF: res = vm_from_f64(fa - fb); break;
+      case GMLRT_SOP_MULF: res = vm_from_f64(fa * fb); break;
+      case GMLRT_SOP_DIVF: res = vm_from_f64(fa / fb); break;
+      case GMLRT_SOP_EQF: res = fa == fb; break;
+      case GMLRT_SOP_LESSF: res = fa < fb; break;
+      case GMLRT_SOP_SQRT: res = vm_from_f64(sqrt(fa)); break;
+      case GMLRT_SOP_FRAC: res = vm_from_f64(vm_frac(fa)); break;
+      case GMLRT_SOP_CLAMPF: res = vm_from_f64(vm_clampf(fa)); break;
+      case GMLRT_SOP_SIN: res = vm_from_f64(vm_sin(fa)); break;
+      case GMLRT_SOP_COS: res = vm_from_f64(vm_cos(fa)); break;
+      case GMLRT_SOP_ASIN: res = vm_from_f64(vm_to_degrees(asin(fa))); break;
+      case GMLRT_SOP_ACOS: res = vm_from_f64(vm_to_degrees(acos(fa))); break;
+      case GMLRT_SOP_SELECT: res = a ? b : OPND(oc); break;
+      case GMLRT_SOP_OUT:
+        if (dst == 0 || dst == 3) {
+          out[dst] = fa;
+          out[dst + 1] = fb;
+          out[dst + 2] = vm_as_f64(OPND(oc));
+        }
+        continue;
+      default: break;
+    }
+    r[dst & (GMLRT_SURF_MAX_REGS - 1)] = res;
+  }
+#undef OPND
+}
+
+}  // namespace gmlrt

@@ -1,0 +1,220 @@
+// Test-only exports: let pytest drive the host front-end and the surface compiler
+// directly (the product ABI has no reason to expose tokens or evaluator stacks).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+
+#include "../../rust-raytracer_amd/csrc/gml_front.hpp"
+#include "../../rust-raytracer_amd/csrc/gmlrt_scene.hpp"
+
+namespace {
+
+std::string fmt_real(double r) {
+  char b[64];
+  std::snprintf(b, sizeof b, "%.17g", r);
+  return b;
+}
+
+std::string dump_token(const gml::Token& t) {
+  switch (t.kind) {
+    case gml::Token::BeginFunction: return "{";
+    case gml::Token::EndFunction: return "}";
+    case gml::Token::BeginArray: return "[";
+    case gml::Token::EndArray: return "]";
+    case gml::Token::Identifier: return "Identifier(" + t.s + ")";
+    case gml::Token::Operator: return std::string("Operator(") + gml::op_name(t.op) + ")";
+    case gml::Token::Binder: return "Binder(" + t.s + ")";
+    case gml::Token::Boolean: return t.b ? "Boolean(true)" : "Boolean(false)";
+    case gml::Token::Real: return "Real(" + fmt_real(t.r) + ")";
+    case gml::Token::Integer: return "Integer(" + std::to_string(t.i) + ")";
+    case gml::Token::Str: return "Str(" + t.s + ")";
+  }
+  return "?";
+}
+
+void dump_ast(const gml::AstList& l, std::string& out) {
+  bool first = true;
+  for (auto& n : l) {
+    if (!first) out += ' ';
+    first = false;
+    if (n.kind == gml::AstNode::Leaf) out += dump_token(n.tok);
+    else {
+      out += n.kind == gml::AstNode::Array ? "Array(" : "Function(";
+      dump_ast(*n.children, out);
+      out += ')';
+    }
+  }
+}
+
+std::string dump_value(const gml::Value& v) {
+  switch (v.kind) {
+    case gml::Value::Closure: return "Closure";
+    case gml::Value::Array: {
+      // storage is reversed; print in source order
+      std::string s = "[";
+      for (size_t i = v.arr.size(); i-- > 0;) { s += dump_value(*v.arr[i]); if (i) s += ' '; }
+      return s + "]";
+    }
+    case gml::Value::Boolean: return v.b ? "true" : "false";
+    case gml::Value::Real: return "Real(" + fmt_real(v.r) + ")";
+    case gml::Value::Integer: return "Integer(" + std::to_string(v.i) + ")";
+    case gml::Value::String: return "Str(" + v.s + ")";
+    case gml::Value::Point: return "Point(" + fmt_real(v.p[0]) + "," + fmt_real(v.p[1]) + "," + fmt_real(v.p[2]) + ")";
+    case gml::Value::NodeV: return "Node";
+    case gml::Value::LightV: {
+      const gml::Light& l = *v.light;
+      return "Light(kind=" + std::to_string((int)l.kind) + ",dir=" + fmt_real(l.dir[0]) + "," + fmt_real(l.dir[1]) + "," +
+             fmt_real(l.dir[2]) + ",color=" + fmt_real(l.color[0]) + "," + fmt_real(l.color[1]) + "," + fmt_real(l.color[2]) + ")";
+    }
+  }
+  return "?";
+}
+
+void put(const std::string& s, char* out, int outlen) {
+  if (outlen > 0) std::snprintf(out, (size_t)outlen, "%s", s.c_str());
+}
+
+}  // namespace
+
+extern "C" {
+
+void th_tokenize(const char* text, char* out, int outlen) {
+  std::string s;
+  try {
+    for (auto& t : gml::tokenize(text)) { if (!s.empty()) s += ' '; s += dump_token(t); }
+  } catch (std::exception& e) { s = std::string("ERROR ") + e.what(); }
+  put(s, out, outlen);
+}
+
+void th_parse(const char* text, char* out, int outlen) {
+  std::string s;
+  try { dump_ast(*gml::parse(gml::tokenize(text)), s); } catch (std::exception& e) { s = std::string("ERROR ") + e.what(); }
+  put(s, out, outlen);
+}
+
+// Runs a program; dumps the final stack (bottom first) and, after " | ", env[var] if var is non-empty.
+void th_run(const char* text, const char* var, char* out, int outlen) {
+  std::string s;
+  try {
+    int renders = 0;
+    gml::Evaluator ev([&](const gml::RenderCall&) { renders++; });
+    gml::Env env;
+    gml::Stack st;
+    gml::run_with_big_stack([&] { ev.run(text, env, st); });
+    for (size_t i = 0; i < st.size(); i++) { if (i) s += ' '; s += dump_value(*st[i]); }
+    if (var && *var) {
+      const gml::ValuePtr* v = env.get(var);
+      s += " | ";
+      s += v ? dump_value(**v) : "<unbound>";
+    }
+    if (renders) s += " | renders=" + std::to_string(renders);
+  } catch (std::exception& e) { s = std::string("ERROR ") + e.what(); }
+  put(s, out, outlen);
+}
+
+void th_preprocess(const char* path, char* out, int outlen) {
+  std::string s;
+  try { s = gml::preprocess_file(path); } catch (std::exception& e) { s = std::string("ERROR ") + e.what(); }
+  put(s, out, outlen);
+}
+
+// For every leaf of render call `idx` of a GML file: evaluates its surface closure
+// both through the tree-walking evaluator and through the compiled bytecode at
+// `samples` random (face,u,v) points.  Returns the number of leaves, or -1.
+// stats[0] = comparisons, stats[1] = bit-exact matches, stats[2] = max abs difference,
+// stats[3] = distinct closures, stats[4] = of those, constant surfaces.
+int th_surface_compare(const char* path, int idx, int samples, unsigned seed, double stats[5], char* err, int errlen) {
+  try {
+    std::string text = gml::preprocess_file(path);
+    std::vector<gml::RenderCall> calls;
+    gml::run_with_big_stack([&] {
+      gml::Evaluator ev([&](const gml::RenderCall& rc) { calls.push_back(rc); });
+      gml::Env env; gml::Stack st;
+      ev.run(text, env, st);
+    });
+    if (idx < 0 || idx >= (int)calls.size()) { put("no such render call", err, errlen); return -1; }
+    struct V : gml::TreeVisitor {
+      std::vector<std::pair<gml::PrimType, gml::ValuePtr>> leaves;
+      void leaf(gml::PrimType p, const gml::ValuePtr& s, const gml::Transform&) override { leaves.emplace_back(p, s); }
+      void op(gml::Rule) override {}
+    } v;
+    gml::walk_postfix(calls[(size_t)idx].scene, v);
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> U(-3.2, 3.2);
+    for (int i = 0; i < 5; i++) stats[i] = 0;
+    std::map<const gml::Value*, gmlrt::SurfaceProgram> progs;
+    gml::Evaluator ev(nullptr);
+    for (auto& lf : v.leaves) {
+      auto it = progs.find(lf.second.get());
+      if (it == progs.end()) {
+        it = progs.emplace(lf.second.get(), gmlrt::compile_surface(*lf.second)).first;
+        stats[3] += 1;
+        if (it->second.constant) stats[4] += 1;
+      }
+      const int nfaces = lf.first == gml::PrimType::Cube ? 6 : lf.first == gml::PrimType::Cylinder ? 3
+                         : lf.first == gml::PrimType::Cone ? 2 : 1;
+      for (int s = 0; s < samples; s++) {
+        const int64_t face = (int64_t)(rng() % (unsigned)nfaces);
+        const double uu = U(rng), vv = U(rng);
+        gml::Vec3 col; double kd, ks, n;
+        ev.call_surface(*lf.second, face, uu, vv, &col, &kd, &ks, &n);
+        double o[6];
+        gmlrt::run_surface_program(it->second, face, uu, vv, o);
+        const double ref[6] = {col[0], col[1], col[2], kd, ks, n};
+        for (int k = 0; k < 6; k++) {
+          stats[0] += 1;
+          if (std::memcmp(&ref[k], &o[k], 8) == 0) stats[1] += 1;
+          const double dd = std::fabs(ref[k] - o[k]);
+          if (dd > stats[2] || dd != dd) stats[2] = dd != dd ? INFINITY : dd;
+        }
+      }
+    }
+    return (int)v.leaves.size();
+  } catch (std::exception& e) {
+    put(e.what(), err, errlen);
+    return -1;
+  }
+}
+
+// Compiles the closure bound to `var` after running `text` and evaluates it both ways.
+int th_surface_eval_text(const char* text, const char* var, long long face, double u, double v, double ref[6],
+                         double got[6], int* is_const, int* n_code, char* err, int errlen) {
+  try {
+    gml::Evaluator ev(nullptr);
+    gml::Env env; gml::Stack st;
+    ev.run(text, env, st);
+    const gml::ValuePtr* c = env.get(var);
+    if (!c) { put("unbound", err, errlen); return -1; }
+    gml::Vec3 col; double kd, ks, n;
+    ev.call_surface(**c, face, u, v, &col, &kd, &ks, &n);
+    ref[0] = col[0]; ref[1] = col[1]; ref[2] = col[2]; ref[3] = kd; ref[4] = ks; ref[5] = n;
+    gmlrt::SurfaceProgram sp = gmlrt::compile_surface(**c);
+    *is_const = sp.constant;
+    *n_code = (int)sp.code.size();
+    gmlrt::run_surface_program(sp, face, u, v, got);
+    return 0;
+  } catch (gmlrt::UnsupportedSurface& e) {
+    put(std::string("UNSUPPORTED ") + e.what(), err, errlen);
+    return -2;
+  } catch (std::exception& e) {
+    put(e.what(), err, errlen);
+    return -1;
+  }
+}
+
+// Transform builder check: applies a sequence of steps (kind, p0,p1,p2)* and returns m and inv_m (row-major 4x4 each).
+void th_transform(const double* steps, int n, double out_m[16], double out_inv[16]) {
+  gml::Transform t;
+  for (int i = 0; i < n; i++) {
+    gml::XformStep s{(gml::XformKind)(int)steps[i * 4], {steps[i * 4 + 1], steps[i * 4 + 2], steps[i * 4 + 3]}};
+    gml::apply_step(t, s);
+  }
+  std::memcpy(out_m, t.m.m, sizeof(double) * 16);
+  std::memcpy(out_inv, t.inv_m.m, sizeof(double) * 16);
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""GPU parity: the HIP render path (through the C ABI) against the f64 CPU oracle.
+
+Tolerance (the project's stated bar for this floating-point path): every channel
+within 1/255 on at least 99.9 % of the pixels and no pixel off by more than 8.
+Because the kernels compute in f64 in the reference's operation order, the
+tests also hold the path to a much tighter figure: ray counts must be EQUAL and
+unquantised pixels must agree to 1e-9.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, image_diff
+
+pytestmark = pytest.mark.gpu
+
+CONFIG_SCENES = ["spheres", "spotlight", "house", "cone-fractal", "chess", "fractal", "large"]
+
+
+def _both(gmlrt, oracle, name, width=None, height=None, depth=None, threads=16):
+    prog = gmlrt.Program(path=os.path.join(SCENES, name + ".gml"))
+    call = prog.calls[0].with_overrides(width, height, depth)
+    img, f64, st = gmlrt.render(call, want_f64=True)
+    op = oracle.OracleProgram(path=os.path.join(SCENES, name + ".gml"))
+    ref, ref64, cnt = op.render(0, w=call.params.width, h=call.params.height, depth=call.params.depth,
+                                threads=threads, want_f64=True)
+    return img, f64, st, ref, ref64, cnt
+
+
+@pytest.mark.parametrize("name", CONFIG_SCENES)
+def test_native_size_matches_oracle(gmlrt, oracle, name):
+    img, f64, st, ref, ref64, cnt = _both(gmlrt, oracle, name)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print(name, "within1=%.6f max=%d differing=%d" % (frac1, maxd, ndiff), st.as_dict())
+    assert frac1 >= 0.999 and maxd <= 8
+    # same rays, ray for ray
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    # unquantised pixels: only libm-class functions (pow/atan2/asin) may differ, in the last ulp
+    both = np.isfinite(f64) & np.isfinite(ref64)
+    assert (np.isfinite(f64) == np.isfinite(ref64)).all()
+    assert np.abs(f64[both] - ref64[both]).max() <= 1e-9
+
+
+def test_chess_depth5_reduced_size(gmlrt, oracle):
+    # the headline configuration's depth, at a size the oracle finishes in seconds
+    img, f64, st, ref, ref64, cnt = _both(gmlrt, oracle, "chess", 480, 270, 5)
+    frac1, maxd, _ = image_diff(img, ref)
+    assert frac1 >= 0.999 and maxd <= 8
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert st.rays_reflect > cnt["primary"] * 0.5  # depth matters in this scene: every surface is a mirror
+
+
+def test_row_partitions_reassemble(gmlrt):
+    # interleaved row tiles rendered separately give the same bytes as one full render
+    prog = gmlrt.Program(path=os.path.join(SCENES, "chess.gml"))
+    call = prog.calls[0].with_overrides(200, 150, 3)
+    full, _, st_full = gmlrt.render(call)
+    h, w = call.params.height, call.params.width
+    scene = gmlrt.DeviceScene(call.blob, 0)
+    import torch
+    for nparts, tile_rows in [(2, 8), (3, 16), (8, 8)]:
+        out = np.zeros_like(full)
+        rays = 0
+        for part in range(nparts):
+            p = gmlrt.Params()
+            ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
+            p.tile_rows, p.part, p.nparts = tile_rows, part, nparts
+            rows = gmlrt.part_row_index(h, tile_rows, part, nparts)
+            buf = torch.zeros((len(rows), w, 3), dtype=torch.uint8, device="cuda:0")
+            st = scene.render_into(p, buf.data_ptr())
+            out[rows] = buf.cpu().numpy()
+            rays += st.rays
+        assert (out == full).all(), (nparts, tile_rows)
+        assert rays == st_full.rays
+    scene.close()
+
+
+def test_repeated_render_is_deterministic(gmlrt):
+    prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
+    a, _, sa = gmlrt.render(prog.calls[0])
+    b, _, sb = gmlrt.render(prog.calls[0])
+    assert (a == b).all() and sa.rays == sb.rays
+
+
+def test_bare_primitive_root_and_exit_first(gmlrt, oracle):
+    # a lone plane seen from inside its half-space: the root list starts with Exit -> black (raytracer.rs:55-57)
+    text = ('{ /v /u /face 1.0 0.5 0.25 point 1.0 0.0 1.0 } plane 0.0 2.0 0.0 translate /p '
+            '0.0 -1.0 0.0 point 1.0 1.0 1.0 point light /l '
+            '1.0 1.0 1.0 point [ l ] p 2 90.0 64 48 "x.ppm" render')
+    call = gmlrt.Program(text=text).calls[0]
+    img, _, st = gmlrt.render(call)
+    ref, _, cnt = oracle.OracleProgram(text=text).render(0)
+    assert (img == ref).all()
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
+def test_full_size_properties(gmlrt):
+    # At the headline size the oracle is too slow to run whole; check size-independent properties instead:
+    # ray accounting, determinism of an interleaved subset against the oracle-checked smaller renders' structure.
+    prog = gmlrt.Program(path=os.path.join(SCENES, "chess.gml"))
+    call = prog.calls[0].with_overrides(3840, 2160, 5)
+    img, _, st = gmlrt.render(call)
+    assert st.rays_primary == 3840 * 2160
+    assert st.rays_reflect <= st.rays_primary * 6 and st.rays_shadow <= st.rays_primary * 6
+    assert img.shape == (2160, 3840, 3) and img.max() > 200 and (img[:200] == 0).mean() > 0.5  # sky rows are black
+
+
+def test_full_size_rows_against_oracle(gmlrt, oracle):
+    # 12 rows of the 3840x2160 depth-5 frame, spread over the image, rendered by the oracle at full width
+    prog = gmlrt.Program(path=os.path.join(SCENES, "chess.gml"))
+    call = prog.calls[0].with_overrides(3840, 2160, 5)
+    img, _, _ = gmlrt.render(call)
+    op = oracle.OracleProgram(path=os.path.join(SCENES, "chess.gml"))
+    ref, _, _ = op.render(0, w=3840, h=2160, depth=5, y0=90, y1=2160, ystep=180, threads=16)
+    rows = list(range(90, 2160, 180))
+    frac1, maxd, ndiff = image_diff(img[rows], ref)
+    print("4K rows: within1=%.6f max=%d differing=%d" % (frac1, maxd, ndiff))
+    assert frac1 >= 0.999 and maxd <= 8
