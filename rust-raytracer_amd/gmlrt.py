@@ -66,6 +66,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgmlrt.so is not built (run `make -C rust-raytracer_amd/csrc`); "
                                "there is no CPU fallback for the render path")
+        # PyTorch ships its own HIP runtime under the same SONAME; a process must hold only one.  Loading torch
+        # first makes this library bind to that copy, so torch tensors and torch.distributed work beside it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
         L.gmlrt_strerror.restype = ctypes.c_char_p
