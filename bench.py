@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chess.gml at 3840x2160, depth 5, through the C ABI on N GPUs.
+
+A step is one full render of the frame: every rank renders its interleaved row
+tiles on its own GPU (scene and output buffers already resident in HBM), then the
+rows are gathered to rank 0 (the only collective).  Rank 0 prints one JSON line.
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
+
+import torch  # noqa: E402  (before gmlrt: one HIP runtime per process)
+import torch.distributed as dist  # noqa: E402
+
+import gmlrt  # noqa: E402
+
+SCENE = os.path.join(ROOT, "scenes", "chess.gml")
+WIDTH, HEIGHT, DEPTH = 3840, 2160, 5
+TILE_ROWS = 8
+
+# Algorithmic flops per primitive test (FMA = 2, sqrt/div = 1, affine 3x4 transforms), including the
+# 45-flop common prologue: sphere, cube, cylinder, cone, plane.  Shading: ~150 per shaded hit.
+F_PRIM = {0: 61, 1: 60, 2: 70, 3: 77, 4: 47}
+F_SHADE = 150
+PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X vector FP64 (the path computes in f64)
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32, the figure the project metric names
+
+
+def scene_flops_per_ray(blob):
+    import struct
+    hdr = struct.unpack_from("<IIQIIIIIIIIQQQQQ", blob, 0)
+    n_leaves, off_leaves = hdr[3], hdr[11]
+    leaf_size = 208
+    total = 0
+    for i in range(n_leaves):
+        (ptype,) = struct.unpack_from("<I", blob, off_leaves + i * leaf_size + 192)
+        total += F_PRIM[ptype]
+    return total, n_leaves
+
+
+def cpu_baseline():
+    """The f64 CPU oracle (restated reference algorithm) on a bounded sample of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    prog = oracle_py.OracleProgram(path=SCENE)
+    # single thread, as the reference runs: every 120th row (18 rows)
+    t0 = time.time()
+    _, _, c1 = prog.render(0, w=WIDTH, h=HEIGHT, depth=DEPTH, y0=60, y1=HEIGHT, ystep=120, threads=1)
+    t1 = time.time() - t0
+    # all cores: every 12th row (180 rows)
+    t0 = time.time()
+    _, _, cn = prog.render(0, w=WIDTH, h=HEIGHT, depth=DEPTH, y0=6, y1=HEIGHT, ystep=12, threads=threads)
+    tn = time.time() - t0
+    r1, rn = sum(c1.values()), sum(cn.values())
+    return {
+        "value": round(rn / tn / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "chess.gml 3840x2160 depth 5, every 12th row (180 rows, %d rays, %.1f s wall on %d threads); "
+                  "single thread on every 120th row: %.4f Mrays/s (%d rays, %.1f s)"
+                  % (rn, tn, threads, r1 / t1 / 1e6, r1, t1),
+        "single_thread_value": round(r1 / t1 / 1e6, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default=SCENE)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- inputs resident in HBM before the timed region
+    call = gmlrt.Program(path=args.scene).calls[0].with_overrides(args.width, args.height, args.depth)
+    w, h = call.params.width, call.params.height
+    flops_per_ray, n_leaves = scene_flops_per_ray(call.blob)
+    scene = gmlrt.DeviceScene(call.blob, local_rank)
+    p = gmlrt.Params()
+    ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
+    p.tile_rows, p.part, p.nparts = TILE_ROWS, rank, world
+    my_rows = gmlrt.part_rows(h, TILE_ROWS, rank, world)
+    max_rows = max(gmlrt.part_rows(h, TILE_ROWS, r, world) for r in range(world))
+    out = torch.zeros((max_rows, w, 3), dtype=torch.uint8, device=dev)  # padded so every rank gathers equal shapes
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = scene.render_into(p, out.data_ptr(), None, stream)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)  # the final framebuffer gather: the only collective
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = kernel_ms = hits = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays
+        hits += st.hits
+        kernel_ms += st.kernel_ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # whole-job figures: max time over ranks, rays summed over ranks
+    agg = torch.tensor([elapsed, kernel_ms / max(args.steps, 1)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([rays, hits], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed_max, kernel_ms_max = agg.tolist()
+    rays_all, hits_all = tot.tolist()
+
+    if rank == 0:
+        ms_per_step = elapsed_max * 1e3 / args.steps
+        rays_per_step = rays_all / args.steps
+        value = rays_per_step / (ms_per_step * 1e-3) / 1e6
+        # roofline of the render kernel on rank 0's GPU: its own rays / its own HIP-event duration
+        my_rays = rays / args.steps
+        my_hits = hits / args.steps
+        my_kernel_ms = kernel_ms / args.steps
+        flops = my_rays * flops_per_ray + my_hits * F_SHADE
+        achieved = flops / (my_kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Mrays/s (primary+shadow+reflect), chess.gml 4K depth 5",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s %dx%d depth %d" % (os.path.basename(args.scene), w, h, call.params.depth),
+                       "leaves": n_leaves, "flops_per_ray": flops_per_ray,
+                       "rays_per_frame": int(rays_per_step), "parallelism": "row-tiles x%d (tile %d rows)" % (world, TILE_ROWS)},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP64_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_VALU_TFLOPS, 5),
+                         "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 5),
+                         "kernel": "render_kernel", "kernel_ms": round(my_kernel_ms, 4),
+                         "kernel_Mrays_per_s": round(my_rays / (my_kernel_ms * 1e-3) / 1e6, 3),
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

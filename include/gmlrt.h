@@ -146,6 +146,7 @@ typedef struct gmlrt_stats {
   double kernel_ms;      /* device time of the render kernel (HIP events; max over GPUs) */
   double total_ms;       /* host wall time of the call                               */
   uint64_t leaf_tests;   /* rays * leaves                                            */
+  uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
   uint32_t reserved;
 } gmlrt_stats;

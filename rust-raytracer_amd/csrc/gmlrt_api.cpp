@@ -252,6 +252,7 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
     total.rays_shadow += P.st.rays_shadow;
     total.rays_reflect += P.st.rays_reflect;
     total.leaf_tests += P.st.leaf_tests;
+    total.hits += P.st.hits;
     if (P.st.kernel_ms > total.kernel_ms) total.kernel_ms = P.st.kernel_ms;
   }
   total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -59,7 +59,7 @@ struct KArgs {
   double* ctx;
   uint32_t ctx_fields;
   unsigned int* next_slot;
-  unsigned long long* ray_counts;  // primary, shadow, reflect
+  unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
 };
 
 struct V3 { double x, y, z; };
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
   int level = 0;      // bounce level of the current view ray
   uint32_t li = 0;    // light being tested
   V3 o = {0, 0, 0}, d = {0, 0, 1};
-  uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0;
+  uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
   bool more = true;   // wave-uniform: pixel slots left to hand out
 
   for (;;) {
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
         ctx_set3(ctx, F_RDIR, d);
         li = 0;
         advance = true;
+        n_hits++;
       }
     } else if (kind == kShadow) {
       // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
@@ -678,11 +679,13 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
     n_primary += (uint32_t)__shfl_down((int)n_primary, off);
     n_shadow += (uint32_t)__shfl_down((int)n_shadow, off);
     n_reflect += (uint32_t)__shfl_down((int)n_reflect, off);
+    n_hits += (uint32_t)__shfl_down((int)n_hits, off);
   }
   if (lane == 0) {
     atomicAdd(&A.ray_counts[0], (unsigned long long)n_primary);
     atomicAdd(&A.ray_counts[1], (unsigned long long)n_shadow);
     atomicAdd(&A.ray_counts[2], (unsigned long long)n_reflect);
+    atomicAdd(&A.ray_counts[3], (unsigned long long)n_hits);
   }
 }
 
@@ -791,7 +794,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.rgbf = (double*)d_rgbf;
 
   if (stats) {
-    stats->rays_primary = stats->rays_shadow = stats->rays_reflect = 0;
+    stats->rays_primary = stats->rays_shadow = stats->rays_reflect = stats->hits = 0;
     stats->kernel_ms = 0.0;
     stats->leaf_tests = 0;
   }
@@ -851,7 +854,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   unsigned long long counts[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(counts, (uint8_t*)s->d_counters + 8, 24, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(counts, (uint8_t*)s->d_counters + 8, 32, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
@@ -859,6 +862,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->rays_primary = counts[0];
     stats->rays_shadow = counts[1];
     stats->rays_reflect = counts[2];
+    stats->hits = counts[3];
     stats->kernel_ms = (double)ms;
     stats->leaf_tests = (counts[0] + counts[1] + counts[2]) * (uint64_t)H.n_leaves;
   }

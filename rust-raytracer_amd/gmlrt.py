@@ -33,11 +33,11 @@ class Params(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("rays_primary", ctypes.c_uint64), ("rays_shadow", ctypes.c_uint64), ("rays_reflect", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("leaf_tests", ctypes.c_uint64),
-                ("n_gpus", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("hits", ctypes.c_uint64), ("n_gpus", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {"primary": self.rays_primary, "shadow": self.rays_shadow, "reflect": self.rays_reflect,
-                "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "leaf_tests": self.leaf_tests,
+                "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "leaf_tests": self.leaf_tests, "hits": self.hits,
                 "n_gpus": self.n_gpus}
 
     @property
