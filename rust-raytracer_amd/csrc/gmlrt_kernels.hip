@@ -11,15 +11,22 @@
 // loads; what differs per lane is the list of entry/exit events each node yields
 // (primitives.rs:253-315), kept on a per-lane stack in device memory.
 //
+// The traversal loop is the hot code and is kept lean in registers; everything
+// that happens once per traced ray (surface bytecode, lights, bounce bookkeeping)
+// lives in one out-of-line function that parks its state in a per-lane context
+// record in device memory.
+//
 // Arithmetic is f64 in the reference's operation order and the file is built with
 // -ffp-contract=off, so intermediate values equal the CPU restatement's bit for
 // bit; only libm-class functions (pow, atan2, asin ...) may differ in the last ulp.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
 #include "gmlrt_device.hpp"
+#include "gmlrt_prims.hpp"
 #include "gmlrt_surface_vm.h"
 
 namespace gmlrt {
@@ -36,12 +43,17 @@ constexpr int kCtxPerLevel = 7;
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
 
+// Read-only scene sections.  Passed to the kernel as separate `const __restrict__`
+// parameters so that wave-uniform reads of them become scalar loads.
+struct ScenePtrs {
+  const gmlrt_leaf* __restrict__ leaves;
+  const uint32_t* __restrict__ nodes;
+  const gmlrt_light* __restrict__ lights;
+  const uint64_t* __restrict__ code;
+  const uint64_t* __restrict__ consts;
+};
+
 struct KArgs {
-  const gmlrt_leaf* leaves;
-  const uint32_t* nodes;
-  const gmlrt_light* lights;
-  const uint64_t* code;
-  const uint64_t* consts;
   uint32_t n_leaves, n_nodes, n_lights, max_stack;
   double amb[3];
   double c_x, c_y, pw;  // camera, raytracer.rs:131-136
@@ -62,220 +74,6 @@ struct KArgs {
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
 };
 
-struct V3 { double x, y, z; };
-__device__ inline V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ inline V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ inline V3 vmul(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ inline V3 vneg(V3 a) { return {-a.x, -a.y, -a.z}; }
-__device__ inline V3 vcmul(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-__device__ inline double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ inline V3 vnormalize(V3 a) { return vmul(a, 1.0 / sqrt(vdot(a, a))); }
-
-// ---------------------------------------------------------------- primitives
-// Ray into object space: primitives.rs:350-354 (same prologue in all five).
-__device__ inline void to_object(const double* __restrict__ im, V3 o, V3 d, double& scale, V3& rd, V3& rp) {
-  V3 td = {im[0] * d.x + im[1] * d.y + im[2] * d.z, im[4] * d.x + im[5] * d.y + im[6] * d.z,
-           im[8] * d.x + im[9] * d.y + im[10] * d.z};
-  scale = 1.0 / sqrt(vdot(td, td));
-  rd = vmul(td, scale);
-  rp = {im[0] * o.x + im[1] * o.y + im[2] * o.z + im[3], im[4] * o.x + im[5] * o.y + im[6] * o.z + im[7],
-        im[8] * o.x + im[9] * o.y + im[10] * o.z + im[11]};
-}
-
-// Result of one primitive test: bit 0 = an Entry event (tA, fA), bit 1 = an Exit event (tB, fB).
-struct PrimHit { int bits; double tA, tB; int fA, fB; };
-
-// primitives.rs:355-393
-__device__ inline PrimHit isect_sphere(V3 p, V3 d) {
-  PrimHit r = {0, 0.0, 0.0, 0, 0};
-  double s = vdot(vneg(p), d);
-  double lsq = vdot(p, p);
-  if (s < 0.0 && lsq > 1.0) return r;
-  double msq = lsq - s * s;
-  if (msq > 1.0) return r;
-  double q = sqrt(1.0 - msq);
-  double t1 = s + q, t2 = s - q;
-  if (t1 > t2) { double t = t1; t1 = t2; t2 = t; }
-  if (t1 > 0.0) { r.bits |= 1; r.tA = t1; }
-  if (t2 > 0.0) { r.bits |= 2; r.tB = t2; }
-  return r;
-}
-
-// primitives.rs:468-534; SLABS = [(3,2),(4,5),(1,0)]
-__device__ inline PrimHit isect_cube(V3 rp, V3 d) {
-  PrimHit r = {0, 0.0, 0.0, 0, 0};
-  const double eps = 1e-15;
-  bool has = false;
-  double tmin = 0.0, tmax = 0.0;
-  int fmin = 0, fmax = 0;
-  const double pe[3] = {0.5 - rp.x, 0.5 - rp.y, 0.5 - rp.z};
-  const double df[3] = {d.x, d.y, d.z};
-  const int f1s[3] = {3, 4, 1}, f2s[3] = {2, 5, 0};
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    int face1 = f1s[i], face2 = f2s[i];
-    const double e = pe[i], f = df[i];
-    if (fabs(f) > eps) {
-      double t1 = (e + 0.5) / f, t2 = (e - 0.5) / f;
-      if (t1 > t2) { double t = t1; t1 = t2; t2 = t; int ff = face1; face1 = face2; face2 = ff; }
-      if (!(has && tmin >= t1)) { tmin = t1; fmin = face1; }
-      if (!(has && tmax <= t2)) { tmax = t2; fmax = face2; }
-      has = true;
-      if (tmin > tmax) return r;
-      if (tmax < 0.0) return r;
-    } else if (-e - 0.5 > 0.0 || -e + 0.5 < 0.0) {
-      return r;
-    }
-  }
-  if (has && tmin > 0.0) { r.bits |= 1; r.tA = tmin; r.fA = fmin; }
-  if (has && tmax > 0.0) { r.bits |= 2; r.tB = tmax; r.fB = fmax; }
-  return r;
-}
-
-// (t, face) pairs ordered like Rust tuples
-__device__ inline bool tf_gt(double ta, int fa, double tb, int fb) { return ta != tb ? ta > tb : fa > fb; }
-__device__ inline bool tf_lt(double ta, int fa, double tb, int fb) { return ta != tb ? ta < tb : fa < fb; }
-
-// primitives.rs:592-606 and 778-792: both roots carry face 0
-__device__ inline bool solve_quadratic(double a, double b, double c, double& t1, double& t2) {
-  double sq = b * b - 4.0 * a * c;
-  if (sq < 0.0) return false;
-  double root = sqrt(sq);
-  double r1 = (-b - root) / (2.0 * a), r2 = (-b + root) / (2.0 * a);
-  if (r1 > r2) { double t = r1; r1 = r2; r2 = t; }
-  t1 = r1; t2 = r2;
-  return true;
-}
-
-// primitives.rs:609-621: bottom cap face 2, top cap face 1
-__device__ inline void cyl_caps(double py, double dy, double& ta, int& fa, double& tb, int& fb) {
-  double dinv = 1.0 / dy;
-  double t1 = -py * dinv, t2 = (-py + 1.0) * dinv;
-  ta = t1; fa = 2; tb = t2; fb = 1;
-  if (t1 > t2) { ta = t2; fa = 1; tb = t1; fb = 2; }
-}
-
-// primitives.rs:633-717
-__device__ inline PrimHit isect_cylinder(V3 p, V3 d) {
-  PrimHit r = {0, 0.0, 0.0, 0, 0};
-  const double eps = 1e-7;
-  double tmin, tmax;
-  int fmin, fmax;
-  if (fabs(d.y) + eps >= 1.0) {
-    double frsd = 1.0 - p.x * p.x - p.z * p.z;
-    if (frsd < 0.0) return r;
-    cyl_caps(p.y, d.y, tmin, fmin, tmax, fmax);
-  } else if (fabs(d.y) < eps) {
-    if (p.y < 0.0 || p.y > 1.0) return r;
-    if (!solve_quadratic(d.x * d.x + d.z * d.z, 2.0 * (p.x * d.x + p.z * d.z), p.x * p.x + p.z * p.z - 1.0, tmin, tmax))
-      return r;
-    fmin = 0; fmax = 0;
-  } else {
-    double tc1, tc2;
-    if (!solve_quadratic(d.x * d.x + d.z * d.z, 2.0 * (p.x * d.x + p.z * d.z), p.x * p.x + p.z * p.z - 1.0, tc1, tc2))
-      return r;
-    cyl_caps(p.y, d.y, tmin, fmin, tmax, fmax);
-    if (tf_gt(tc1, 0, tmin, fmin)) { tmin = tc1; fmin = 0; }
-    if (tf_lt(tc2, 0, tmax, fmax)) { tmax = tc2; fmax = 0; }
-    if (tmin > tmax) return r;
-    if (tmax < 0.0) return r;
-  }
-  if (tmin > 0.0) { r.bits |= 1; r.tA = tmin; r.fA = fmin; }
-  if (tmax > 0.0) { r.bits |= 2; r.tB = tmax; r.fB = fmax; }
-  return r;
-}
-
-// primitives.rs:805-887
-__device__ inline PrimHit isect_cone(V3 p, V3 d) {
-  PrimHit r = {0, 0.0, 0.0, 0, 0};
-  double tc1, tc2;
-  if (!solve_quadratic(d.x * d.x + d.z * d.z - d.y * d.y, 2.0 * (p.x * d.x + p.z * d.z - p.y * d.y),
-                       p.x * p.x + p.z * p.z - p.y * p.y, tc1, tc2))
-    return r;
-  const double cminy = p.y + tc1 * d.y, cmaxy = p.y + tc2 * d.y;
-  const bool k1 = 0.0 <= cminy && cminy <= 1.0, k2 = 0.0 <= cmaxy && cmaxy <= 1.0;
-  double ta, tb;
-  int fa = 0, fb = 0;
-  if (k1 && k2) {
-    ta = tc1; tb = tc2;
-  } else if (k1 || k2) {
-    // one hit on the mantle, the other on the base cap (face 1); two-element sort
-    // that swaps when the cap is nearer or the comparison is unordered
-    ta = k1 ? tc1 : tc2;
-    tb = (-p.y + 1.0) / d.y;
-    fb = 1;
-    if (!(tb >= ta)) { double t = ta; ta = tb; tb = t; fa = 1; fb = 0; }
-  } else {
-    return r;
-  }
-  if (ta > 0.0) { r.bits |= 1; r.tA = ta; r.fA = fa; }
-  if (tb > 0.0) { r.bits |= 2; r.tB = tb; r.fB = fb; }
-  return r;
-}
-
-// primitives.rs:945-981: a single event, Entry when the ray heads into y <= 0
-__device__ inline PrimHit isect_plane(V3 p, V3 d) {
-  PrimHit r = {0, 0.0, 0.0, 0, 0};
-  const double denom = d.y;
-  if (fabs(denom) < 1e-7) return r;
-  const double t = -p.y / denom;
-  if (t < 0.0) return r;
-  if (denom > 0.0) { r.bits = 2; r.tB = t; }
-  else { r.bits = 1; r.tA = t; }
-  return r;
-}
-
-__device__ inline PrimHit isect_prim(uint32_t type, V3 rp, V3 rd) {
-  switch (type) {
-    case GMLRT_SPHERE: return isect_sphere(rp, rd);
-    case GMLRT_CUBE: return isect_cube(rp, rd);
-    case GMLRT_CYLINDER: return isect_cylinder(rp, rd);
-    case GMLRT_CONE: return isect_cone(rp, rd);
-    default: return isect_plane(rp, rd);
-  }
-}
-
-// (u, v) of primitives.rs:403-412, 544-555, 726-734, 897-904, 989-996
-__device__ inline void prim_uv(uint32_t type, int face, V3 o, double& u, double& v) {
-  switch (type) {
-    case GMLRT_SPHERE: v = (o.y + 1.0) / 2.0; u = atan2(o.x, o.z); break;
-    case GMLRT_CUBE:
-      if (face <= 1) { u = o.x; v = o.y; }
-      else if (face <= 3) { u = o.z; v = o.y; }
-      else { u = o.x; v = o.z; }
-      break;
-    case GMLRT_CYLINDER:
-    case GMLRT_CONE:
-      if (face == 0) { u = atan2(o.x, o.z); v = o.y; }
-      else { u = (o.x + 1.0) / 2.0; v = (o.z + 1.0) / 2.0; }
-      break;
-    default: u = o.x; v = o.z; break;
-  }
-}
-
-// object-space normal of primitives.rs:414-420, 557-565, 735-743, 906-913, 998-1006
-__device__ inline V3 prim_normal(uint32_t type, int face, V3 o) {
-  switch (type) {
-    case GMLRT_SPHERE: return o;
-    case GMLRT_CUBE:
-      switch (face) {
-        case 0: return {0.0, 0.0, -1.0};
-        case 1: return {0.0, 0.0, 1.0};
-        case 2: return {-1.0, 0.0, 0.0};
-        case 3: return {1.0, 0.0, 0.0};
-        case 4: return {0.0, 1.0, 0.0};
-        default: return {0.0, -1.0, 0.0};
-      }
-    case GMLRT_CYLINDER:
-      if (face == 0) return {o.x, 0.0, o.z};
-      return face == 1 ? V3{0.0, 1.0, 0.0} : V3{0.0, -1.0, 0.0};
-    case GMLRT_CONE:
-      if (face == 0) return {o.x, -o.y, o.z};
-      return {0.0, 1.0, 0.0};
-    default: return {0.0, 1.0, 0.0};
-  }
-}
-
 // ---------------------------------------------------------------- CSG traversal
 struct Hit { bool any; double dist; uint32_t meta; };
 
@@ -287,8 +85,8 @@ __device__ inline bool csg_rule(uint32_t rule, bool a, bool b) {
 // above the other on the lane's event stack (A at a0, B right after it).  Both
 // inputs are already sorted, so the stable sort of their concatenation is a merge
 // that takes A on ties.  Output goes above B and is then moved down onto A.
-__device__ inline uint32_t merge_lists(uint32_t rule, double* __restrict__ evD, uint32_t* __restrict__ evM, uint32_t a0,
-                                       uint32_t la, uint32_t lb) {
+__device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__ evD, uint32_t* __restrict__ evM,
+                                             uint32_t a0, uint32_t la, uint32_t lb) {
   const uint32_t b0 = a0 + la, out0 = b0 + lb;
   uint32_t i = 0, j = 0, k = 0;
   bool in1 = false, in2 = false, inside = false;
@@ -339,15 +137,15 @@ __device__ inline uint32_t merge_lists(uint32_t rule, double* __restrict__ evD, 
 // `lens` holds, per operand-stack level and lane, the length of that list; bit 15
 // marks a two-event primitive list shorter than 1e-10 (it vanishes in any operator
 // whose other operand is empty, primitives.rs:295-298).
-__device__ inline Hit intersect_scene(const KArgs& A, bool active, V3 o, V3 d, double* __restrict__ evD,
+__device__ inline Hit intersect_scene(const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes,
+                                      uint32_t n_nodes, bool active, V3 o, V3 d, double* __restrict__ evD,
                                       uint32_t* __restrict__ evM, uint16_t* __restrict__ lens) {
   Hit h = {false, 0.0, 0u};
-  if (A.n_nodes == 1) {
+  if (n_nodes == 1) {
     // The root is a bare primitive: its raw list is what trace sees, a lone Exit included.
-    const gmlrt_leaf* L = A.leaves;
     double scale; V3 rd, rp;
-    to_object(L->inv_m, o, d, scale, rd, rp);
-    PrimHit ph = isect_prim(L->type, rp, rd);
+    to_object(leaves->inv_m, o, d, scale, rd, rp);
+    PrimHit ph = isect_prim(leaves->type, rp, rd);
     if (active && ph.bits) {
       h.any = true;
       if (ph.bits & 1) { h.dist = scale * ph.tA; h.meta = ((uint32_t)ph.fA << kFaceShift); }
@@ -358,10 +156,10 @@ __device__ inline Hit intersect_scene(const KArgs& A, bool active, V3 o, V3 d, d
   uint32_t sp = 0;     // events on this lane's stack
   uint32_t level = 0;  // operand stack depth (wave-uniform)
   const int tid = threadIdx.x;
-  for (uint32_t pc = 0; pc < A.n_nodes; pc++) {
-    const uint32_t word = A.nodes[pc];
+  for (uint32_t pc = 0; pc < n_nodes; pc++) {
+    const uint32_t word = nodes[pc];
     if ((word >> 30) == 0) {
-      const gmlrt_leaf* L = A.leaves + (word & 0x3FFFFFFFu);
+      const gmlrt_leaf* __restrict__ L = leaves + (word & 0x3FFFFFFFu);
       double scale; V3 rd, rp;
       to_object(L->inv_m, o, d, scale, rd, rp);
       PrimHit ph = isect_prim(L->type, rp, rd);
@@ -461,7 +259,181 @@ __device__ inline void ctx_set3(double* ctx, int f, V3 v) { CTX(f) = v.x; CTX(f 
 enum { F_POS = 0, F_NRM = 3, F_SC = 6, F_KD = 9, F_KS = 10, F_N = 11, F_C = 12, F_DIFF = 15, F_SPEC = 18,
        F_RPOS = 21, F_RDIR = 24 };
 
-__global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
+// What a lane carries from one traversal to the next.
+struct LaneState {
+  V3 o, d;        // ray to traverse
+  int kind;       // RayKind
+  uint32_t pix;   // output index (row-in-partition * w + x)
+  int level;      // bounce level of the current view ray
+  uint32_t li;    // light being tested
+  uint32_t n_shadow, n_reflect, n_hits;
+};
+
+// Everything trace() does around its intersect calls (raytracer.rs:53-110), cut at
+// those calls: consumes the traversal result of the ray the lane holds and leaves
+// either the next ray to traverse in S or an idle lane with its pixel written.
+__device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, const ScenePtrs P, const KArgs A,
+                                                  double* __restrict__ ctx) {
+  bool advance = false, finish = false;
+  V3 C = {0.0, 0.0, 0.0};  // value of trace() at S.level when finish is set
+
+  if (S.kind == kView) {
+    if (!h.any || (h.meta & kCurExit)) {
+      finish = true;  // raytracer.rs:55-57, 108-110
+    } else {
+      // ---- raytracer.rs:58-68: surface, position, normal of the hit
+      const gmlrt_leaf* L = P.leaves + (h.meta & kLeafMask);
+      const int face = (int)((h.meta >> kFaceShift) & 7u);
+      double scale; V3 rd, rp;
+      to_object(L->inv_m, S.o, S.d, scale, rd, rp);
+      const uint32_t type = L->type;
+      PrimHit ph = isect_prim(type, rp, rd);
+      const double od = (h.meta & kOrigExit) ? ph.tB : ph.tA;
+      const V3 opos = vadd(rp, vmul(rd, od));
+      double u, v;
+      prim_uv(type, face, opos, u, v);
+      double s6[6];
+      const uint32_t mycode = L->surf_code;
+      const uint64_t* kc = P.consts + L->surf_const;
+      if (mycode == GMLRT_SURF_CONST) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
+      } else {
+        // run each distinct program once for the lanes that share it
+        bool pending = true;
+        while (pending) {
+          const uint32_t cur = __builtin_amdgcn_readfirstlane(mycode);
+          if (mycode == cur) {
+            // the bytecode registers live in the lane's context record, after the bounce stack
+            surface_vm(P.code + cur, kc, (int64_t)face, u, v, s6,
+                       (uint64_t*)(ctx + (size_t)(A.ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), kWave);
+            pending = false;
+          }
+        }
+      }
+      const V3 sc = {s6[0], s6[1], s6[2]};
+      const double kd = s6[3], ks = s6[4], sn = s6[5];
+      const V3 c = vmul(vcmul({A.amb[0], A.amb[1], A.amb[2]}, sc), kd);  // get_ambient
+      const double* m = L->m;
+      const V3 pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3],
+                      m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
+                      m[8] * opos.x + m[9] * opos.y + m[10] * opos.z + m[11]};
+      const V3 no = prim_normal(type, face, opos);
+      const double* im = L->inv_m;  // transform_normal: transpose(inv_m) * n  (transform.rs:34-36)
+      V3 nw = {im[0] * no.x + im[4] * no.y + im[8] * no.z, im[1] * no.x + im[5] * no.y + im[9] * no.z,
+               im[2] * no.x + im[6] * no.y + im[10] * no.z};
+      V3 normal = vnormalize(nw);
+      if (((h.meta & kCurExit) != 0) != ((h.meta & kOrigExit) != 0)) normal = vneg(normal);
+      ctx_set3(ctx, F_POS, pos);
+      ctx_set3(ctx, F_NRM, normal);
+      ctx_set3(ctx, F_SC, sc);
+      CTX(F_KD) = kd; CTX(F_KS) = ks; CTX(F_N) = sn;
+      ctx_set3(ctx, F_C, c);
+      ctx_set3(ctx, F_DIFF, {0.0, 0.0, 0.0});
+      ctx_set3(ctx, F_SPEC, {0.0, 0.0, 0.0});
+      ctx_set3(ctx, F_RPOS, S.o);
+      ctx_set3(ctx, F_RDIR, S.d);
+      S.li = 0;
+      S.n_hits++;
+      advance = true;
+    }
+  } else if (S.kind == kShadow) {
+    // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
+    const gmlrt_light& l = P.lights[S.li];
+    const V3 pos = ctx_get3(ctx, F_POS);
+    V3 ldir; bool has_ld; double ld;
+    light_direction(l, pos, ldir, has_ld, ld);
+    bool lit = !h.any;
+    if (!lit && has_ld && ld < h.dist) lit = true;
+    if (lit) {
+      const V3 normal = ctx_get3(ctx, F_NRM);
+      const V3 sc = ctx_get3(ctx, F_SC);
+      const double kd = CTX(F_KD), ks = CTX(F_KS);
+      const double df = vdot(normal, ldir);
+      const V3 ic = vcmul(sc, light_intensity(l, pos));
+      if (kd > 0.0) ctx_set3(ctx, F_DIFF, vadd(ctx_get3(ctx, F_DIFF), vmul(ic, df)));
+      if (ks > 0.0) {
+        // get_specular, raytracer.rs:34-42
+        const V3 raypos = ctx_get3(ctx, F_RPOS);
+        const V3 halfway = vnormalize(vadd(ldir, vnormalize(vsub(raypos, pos))));
+        const double sp = vdot(normal, halfway);
+        if (sp > 0.0) ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), vmul(ic, pow(sp, CTX(F_N)))));
+        else ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), {0.0, 0.0, 0.0}));
+      }
+    }
+    S.li++;
+    advance = true;
+  }
+
+  if (advance) {
+    // ---- raytracer.rs:69-74: next light that faces the surface gets a shadow ray
+    const V3 pos = ctx_get3(ctx, F_POS);
+    const V3 normal = ctx_get3(ctx, F_NRM);
+    bool spawned = false;
+    while (S.li < A.n_lights) {
+      V3 ldir; bool has_ld; double ld;
+      light_direction(P.lights[S.li], pos, ldir, has_ld, ld);
+      if (vdot(normal, ldir) > 0.0) {
+        S.o = vadd(pos, vmul(ldir, 1e-7));
+        S.d = ldir;
+        S.kind = kShadow;
+        S.n_shadow++;
+        spawned = true;
+        break;
+      }
+      S.li++;
+    }
+    if (!spawned) {
+      // ---- raytracer.rs:96-107
+      const double kd = CTX(F_KD), ks = CTX(F_KS);
+      const V3 diff = vmul(ctx_get3(ctx, F_DIFF), kd);
+      const V3 spec = vmul(ctx_get3(ctx, F_SPEC), ks);
+      const V3 c = vadd(ctx_get3(ctx, F_C), vadd(diff, spec));
+      if (ks > 0.0 && (A.depth - S.level) > 0) {
+        const V3 raydir = ctx_get3(ctx, F_RDIR);
+        const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
+        // park (c, sc, ks) until the bounce below returns
+        const int f = kCtxFixed + S.level * kCtxPerLevel;
+        ctx_set3(ctx, f, c);
+        ctx_set3(ctx, f + 3, ctx_get3(ctx, F_SC));
+        CTX(f + 6) = ks;
+        S.o = vadd(pos, vmul(refl, 1e-7));
+        S.d = refl;
+        S.kind = kView;
+        S.level++;
+        S.n_reflect++;
+      } else {
+        C = c;
+        finish = true;
+      }
+    }
+  }
+
+  if (finish) {
+    // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
+    for (int lv = S.level - 1; lv >= 0; lv--) {
+      const int f = kCtxFixed + lv * kCtxPerLevel;
+      const V3 c = ctx_get3(ctx, f);
+      const V3 sc = ctx_get3(ctx, f + 3);
+      const double ks = CTX(f + 6);
+      C = vadd(c, vmul(vcmul(C, sc), ks));
+    }
+    const size_t oidx = (size_t)S.pix * 3;
+    A.rgb8[oidx] = quantise(C.x);
+    A.rgb8[oidx + 1] = quantise(C.y);
+    A.rgb8[oidx + 2] = quantise(C.z);
+    if (A.rgbf) { A.rgbf[oidx] = C.x; A.rgbf[oidx + 1] = C.y; A.rgbf[oidx + 2] = C.z; }
+    S.kind = kIdle;
+  }
+  return S;
+}
+
+#ifndef GMLRT_WAVES_PER_SIMD
+#define GMLRT_WAVES_PER_SIMD 6  // measured on chess 4K: 3 -> 616, 4 -> 693, 5 -> 731, 6 -> 749, 8 -> 454 Mrays/s
+#endif
+__global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
+    const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
+    const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const KArgs A) {
   extern __shared__ uint16_t lens[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -469,25 +441,29 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
   double* __restrict__ evD = A.ev_dist + wave * A.ev_cap * kWave + lane;
   uint32_t* __restrict__ evM = A.ev_meta + wave * A.ev_cap * kWave + lane;
   double* __restrict__ ctx = A.ctx + wave * A.ctx_fields * kWave + lane;
+  const ScenePtrs P = {leaves, nodes, lights, code, consts};
 
-  int kind = kIdle;
-  uint32_t pix = 0;   // output index (row-in-partition * w + x)
-  int level = 0;      // bounce level of the current view ray
-  uint32_t li = 0;    // light being tested
-  V3 o = {0, 0, 0}, d = {0, 0, 1};
-  uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
+  LaneState S;
+  S.o = {0, 0, 0};
+  S.d = {0, 0, 1};
+  S.kind = kIdle;
+  S.pix = 0;
+  S.level = 0;
+  S.li = 0;
+  S.n_shadow = S.n_reflect = S.n_hits = 0;
+  uint32_t n_primary = 0;
   bool more = true;   // wave-uniform: pixel slots left to hand out
 
   for (;;) {
     // ---- hand new pixels to idle lanes
     if (more) {
-      const unsigned long long idle = __ballot(kind == kIdle);
+      const unsigned long long idle = __ballot(S.kind == kIdle);
       if (idle) {
         const uint32_t cnt = (uint32_t)__popcll(idle);
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.next_slot, cnt);
         base = (uint32_t)__shfl((int)base, 0);
-        if (kind == kIdle) {
+        if (S.kind == kIdle) {
           const uint32_t slot = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
           if (slot < A.n_slots) {
             // slot -> 8x8 tile -> pixel of this partition's packed rows
@@ -503,11 +479,11 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
               // raytracer.rs:138-142
               const double xf = (double)x, yf = (double)y;
               V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
-              o = {0.0, 0.0, -1.0};
-              d = vnormalize(dir);
-              kind = kView;
-              level = 0;
-              pix = yl * (uint32_t)A.w + x;
+              S.o = {0.0, 0.0, -1.0};
+              S.d = vnormalize(dir);
+              S.kind = kView;
+              S.level = 0;
+              S.pix = yl * (uint32_t)A.w + x;
               n_primary++;
             }
           }
@@ -515,166 +491,19 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs A) {
         if (base + cnt >= A.n_slots) more = false;
       }
     }
-    if (!__ballot(kind != kIdle)) {
+    if (!__ballot(S.kind != kIdle)) {
       if (!more) break;
       continue;
     }
 
     // ---- one scene traversal for whatever ray each lane holds
-    const Hit h = intersect_scene(A, kind != kIdle, o, d, evD, evM, lens);
-
-    bool advance = false, finish = false;
-    V3 C = {0.0, 0.0, 0.0};  // value of trace() at `level` when finish is set
-
-    if (kind == kView) {
-      if (!h.any || (h.meta & kCurExit)) {
-        finish = true;  // raytracer.rs:55-57, 108-110
-      } else {
-        // ---- raytracer.rs:58-68: surface, position, normal of the hit
-        const gmlrt_leaf* L = A.leaves + (h.meta & kLeafMask);
-        const int face = (int)((h.meta >> kFaceShift) & 7u);
-        double scale; V3 rd, rp;
-        to_object(L->inv_m, o, d, scale, rd, rp);
-        const uint32_t type = L->type;
-        PrimHit ph = isect_prim(type, rp, rd);
-        const double od = (h.meta & kOrigExit) ? ph.tB : ph.tA;
-        const V3 opos = vadd(rp, vmul(rd, od));
-        double u, v;
-        prim_uv(type, face, opos, u, v);
-        double s6[6];
-        const uint32_t mycode = L->surf_code;
-        const uint64_t* kc = A.consts + L->surf_const;
-        if (mycode == GMLRT_SURF_CONST) {
-#pragma unroll
-          for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
-        } else {
-          // run each distinct program once for the lanes that share it
-          bool pending = true;
-          while (pending) {
-            const uint32_t cur = __builtin_amdgcn_readfirstlane(mycode);
-            if (mycode == cur) {
-              surface_vm(A.code + cur, kc, (int64_t)face, u, v, s6);
-              pending = false;
-            }
-          }
-        }
-        const V3 sc = {s6[0], s6[1], s6[2]};
-        const double kd = s6[3], ks = s6[4], sn = s6[5];
-        const V3 c = vmul(vcmul({A.amb[0], A.amb[1], A.amb[2]}, sc), kd);  // get_ambient
-        const double* m = L->m;
-        const V3 pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3],
-                        m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
-                        m[8] * opos.x + m[9] * opos.y + m[10] * opos.z + m[11]};
-        const V3 no = prim_normal(type, face, opos);
-        const double* im = L->inv_m;  // transform_normal: transpose(inv_m) * n  (transform.rs:34-36)
-        V3 nw = {im[0] * no.x + im[4] * no.y + im[8] * no.z, im[1] * no.x + im[5] * no.y + im[9] * no.z,
-                 im[2] * no.x + im[6] * no.y + im[10] * no.z};
-        V3 normal = vnormalize(nw);
-        if (((h.meta & kCurExit) != 0) != ((h.meta & kOrigExit) != 0)) normal = vneg(normal);
-        ctx_set3(ctx, F_POS, pos);
-        ctx_set3(ctx, F_NRM, normal);
-        ctx_set3(ctx, F_SC, sc);
-        CTX(F_KD) = kd; CTX(F_KS) = ks; CTX(F_N) = sn;
-        ctx_set3(ctx, F_C, c);
-        ctx_set3(ctx, F_DIFF, {0.0, 0.0, 0.0});
-        ctx_set3(ctx, F_SPEC, {0.0, 0.0, 0.0});
-        ctx_set3(ctx, F_RPOS, o);
-        ctx_set3(ctx, F_RDIR, d);
-        li = 0;
-        advance = true;
-        n_hits++;
-      }
-    } else if (kind == kShadow) {
-      // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
-      const gmlrt_light& l = A.lights[li];
-      const V3 pos = ctx_get3(ctx, F_POS);
-      V3 ldir; bool has_ld; double ld;
-      light_direction(l, pos, ldir, has_ld, ld);
-      bool lit = !h.any;
-      if (!lit && has_ld && ld < h.dist) lit = true;
-      if (lit) {
-        const V3 normal = ctx_get3(ctx, F_NRM);
-        const V3 sc = ctx_get3(ctx, F_SC);
-        const double kd = CTX(F_KD), ks = CTX(F_KS);
-        const double df = vdot(normal, ldir);
-        const V3 ic = vcmul(sc, light_intensity(l, pos));
-        if (kd > 0.0) ctx_set3(ctx, F_DIFF, vadd(ctx_get3(ctx, F_DIFF), vmul(ic, df)));
-        if (ks > 0.0) {
-          // get_specular, raytracer.rs:34-42
-          const V3 raypos = ctx_get3(ctx, F_RPOS);
-          const V3 halfway = vnormalize(vadd(ldir, vnormalize(vsub(raypos, pos))));
-          const double sp = vdot(normal, halfway);
-          if (sp > 0.0) ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), vmul(ic, pow(sp, CTX(F_N)))));
-          else ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), {0.0, 0.0, 0.0}));
-        }
-      }
-      li++;
-      advance = true;
-    }
-
-    if (advance) {
-      // ---- raytracer.rs:69-74: next light that faces the surface gets a shadow ray
-      const V3 pos = ctx_get3(ctx, F_POS);
-      const V3 normal = ctx_get3(ctx, F_NRM);
-      bool spawned = false;
-      while (li < A.n_lights) {
-        V3 ldir; bool has_ld; double ld;
-        light_direction(A.lights[li], pos, ldir, has_ld, ld);
-        if (vdot(normal, ldir) > 0.0) {
-          o = vadd(pos, vmul(ldir, 1e-7));
-          d = ldir;
-          kind = kShadow;
-          n_shadow++;
-          spawned = true;
-          break;
-        }
-        li++;
-      }
-      if (!spawned) {
-        // ---- raytracer.rs:96-107
-        const double kd = CTX(F_KD), ks = CTX(F_KS);
-        const V3 diff = vmul(ctx_get3(ctx, F_DIFF), kd);
-        const V3 spec = vmul(ctx_get3(ctx, F_SPEC), ks);
-        const V3 c = vadd(ctx_get3(ctx, F_C), vadd(diff, spec));
-        if (ks > 0.0 && (A.depth - level) > 0) {
-          const V3 raydir = ctx_get3(ctx, F_RDIR);
-          const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
-          // park (c, sc, ks) until the bounce below returns
-          const int f = kCtxFixed + level * kCtxPerLevel;
-          ctx_set3(ctx, f, c);
-          ctx_set3(ctx, f + 3, ctx_get3(ctx, F_SC));
-          CTX(f + 6) = ks;
-          o = vadd(pos, vmul(refl, 1e-7));
-          d = refl;
-          kind = kView;
-          level++;
-          n_reflect++;
-        } else {
-          C = c;
-          finish = true;
-        }
-      }
-    }
-
-    if (finish) {
-      // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
-      for (int lv = level - 1; lv >= 0; lv--) {
-        const int f = kCtxFixed + lv * kCtxPerLevel;
-        const V3 c = ctx_get3(ctx, f);
-        const V3 sc = ctx_get3(ctx, f + 3);
-        const double ks = CTX(f + 6);
-        C = vadd(c, vmul(vcmul(C, sc), ks));
-      }
-      const size_t oidx = (size_t)pix * 3;
-      A.rgb8[oidx] = quantise(C.x);
-      A.rgb8[oidx + 1] = quantise(C.y);
-      A.rgb8[oidx + 2] = quantise(C.z);
-      if (A.rgbf) { A.rgbf[oidx] = C.x; A.rgbf[oidx + 1] = C.y; A.rgbf[oidx + 2] = C.z; }
-      kind = kIdle;
-    }
+    const Hit h = intersect_scene(leaves, nodes, A.n_nodes, S.kind != kIdle, S.o, S.d, evD, evM, lens);
+    // ---- then the per-ray bookkeeping, out of line
+    if (S.kind != kIdle) S = after_traversal(S, h, P, A, ctx);
   }
 
   // ---- ray counters: one atomic per wave and kind
+  uint32_t n_shadow = S.n_shadow, n_reflect = S.n_reflect, n_hits = S.n_hits;
   for (int off = 32; off > 0; off >>= 1) {
     n_primary += (uint32_t)__shfl_down((int)n_primary, off);
     n_shadow += (uint32_t)__shfl_down((int)n_shadow, off);
@@ -758,13 +587,14 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   const gmlrt_blob_header& H = s->hdr;
   const uint8_t* base = (const uint8_t*)s->d_blob;
 
+  const gmlrt_leaf* d_leaves = (const gmlrt_leaf*)(base + H.off_leaves);
+  const uint32_t* d_nodes = (const uint32_t*)(base + H.off_nodes);
+  const gmlrt_light* d_lights = (const gmlrt_light*)(base + H.off_lights);
+  const uint64_t* d_code = (const uint64_t*)(base + H.off_code);
+  const uint64_t* d_consts = (const uint64_t*)(base + H.off_consts);
+
   KArgs A;
   std::memset(&A, 0, sizeof(A));
-  A.leaves = (const gmlrt_leaf*)(base + H.off_leaves);
-  A.nodes = (const uint32_t*)(base + H.off_nodes);
-  A.lights = (const gmlrt_light*)(base + H.off_lights);
-  A.code = (const uint64_t*)(base + H.off_code);
-  A.consts = (const uint64_t*)(base + H.off_consts);
   A.n_leaves = H.n_leaves;
   A.n_nodes = H.n_nodes;
   A.n_lights = H.n_lights;
@@ -816,7 +646,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // ---- workspace
   const size_t lanes = (size_t)grid * kBlock;
   const size_t ev_cap = H.max_events < 2 ? 2 : H.max_events;
-  const size_t ctx_fields = (size_t)kCtxFixed + (size_t)kCtxPerLevel * (size_t)(p.depth + 1);
+  // shading context + one parked record per bounce level + the surface bytecode's registers (at the end)
+  const size_t ctx_fields =
+      (size_t)kCtxFixed + (size_t)kCtxPerLevel * (size_t)(p.depth + 1) + (size_t)GMLRT_SURF_MAX_REGS;
   if (lanes > s->lanes_alloc || ev_cap > s->ev_slots_alloc) {
     (void)hipFree(s->d_ev_dist);
     (void)hipFree(s->d_ev_meta);
@@ -850,7 +682,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
 
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, A);
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                     d_code, d_consts, A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   unsigned long long counts[4] = {0, 0, 0, 0};

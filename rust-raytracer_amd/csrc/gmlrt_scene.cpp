@@ -496,7 +496,8 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
     for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
     return;
   }
-  surface_vm(p.code.data(), p.consts.data(), face, u, v, out);
+  uint64_t regs[GMLRT_SURF_MAX_REGS];
+  surface_vm(p.code.data(), p.consts.data(), face, u, v, out, regs, 1);
 }
 
 // ============================================================== flattening

@@ -46,13 +46,14 @@ GMLRT_HD double vm_frac(double x) { return x - trunc(x); }
 GMLRT_HD double vm_clampf(double x) { return fmin(fmax(x, 0.0), 1.0); }
 
 // Runs `code` until GMLRT_SOP_END.  consts points at this surface's first constant.
+// `r` is storage for GMLRT_SURF_MAX_REGS 8-byte registers, register i at r[i * rstride]
+// (the device hands in a lane-strided slice of its context record, the host a plain array).
 GMLRT_HD void surface_vm(const uint64_t* code, const uint64_t* consts, int64_t face, double u, double v,
-                         double out[6]) {
-  uint64_t r[GMLRT_SURF_MAX_REGS];
+                         double out[6], uint64_t* r, size_t rstride) {
   r[0] = (uint64_t)face;
-  r[1] = vm_from_f64(u);
-  r[2] = vm_from_f64(v);
-#define OPND(x) (((x) & 0x8000u) ? consts[(x) & 0x7FFFu] : r[(x) & (GMLRT_SURF_MAX_REGS - 1)])
+  r[1 * rstride] = vm_from_f64(u);
+  r[2 * rstride] = vm_from_f64(v);
+#define OPND(x) (((x) & 0x8000u) ? consts[(x) & 0x7FFFu] : r[(size_t)((x) & (GMLRT_SURF_MAX_REGS - 1)) * rstride])
   for (uint32_t pc = 0;; pc++) {
     const uint64_t w = code[pc];
     const uint32_t op = (uint32_t)(w & 0xFF);
@@ -89,16 +90,15 @@ GMLRT_HD void surface_vm(const uint64_t* code, const uint64_t* consts, int64_t f
       case GMLRT_SOP_ASIN: res = vm_from_f64(vm_to_degrees(asin(fa))); break;
       case GMLRT_SOP_ACOS: res = vm_from_f64(vm_to_degrees(acos(fa))); break;
       case GMLRT_SOP_SELECT: res = a ? b : OPND(oc); break;
-      case GMLRT_SOP_OUT:
-        if (dst == 0 || dst == 3) {
-          out[dst] = fa;
-          out[dst + 1] = fb;
-          out[dst + 2] = vm_as_f64(OPND(oc));
-        }
+      case GMLRT_SOP_OUT: {
+        const double fc = vm_as_f64(OPND(oc));
+        if (dst == 0) { out[0] = fa; out[1] = fb; out[2] = fc; }
+        else if (dst == 3) { out[3] = fa; out[4] = fb; out[5] = fc; }
         continue;
+      }
       default: break;
     }
-    r[dst & (GMLRT_SURF_MAX_REGS - 1)] = res;
+    r[(size_t)(dst & (GMLRT_SURF_MAX_REGS - 1)) * rstride] = res;
   }
 #undef OPND
 }

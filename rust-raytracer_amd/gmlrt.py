@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmlrt.so")
+LIB_PATH = os.environ.get("GMLRT_LIB") or os.path.join(_HERE, "libgmlrt.so")  # GMLRT_LIB: try a variant build
 
 # every symbol include/gmlrt.h declares
 EXPORTS = [
