@@ -23,6 +23,7 @@ import torch  # noqa: E402  (before gmlrt: one HIP runtime per process)
 import torch.distributed as dist  # noqa: E402
 
 import gmlrt  # noqa: E402
+import rowtiles  # noqa: E402
 
 SCENE = os.path.join(ROOT, "scenes", "chess.gml")
 WIDTH, HEIGHT, DEPTH = 3840, 2160, 5
@@ -103,16 +104,15 @@ def main():
     p = gmlrt.Params()
     ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
     p.tile_rows, p.part, p.nparts = TILE_ROWS, rank, world
-    my_rows = gmlrt.part_rows(h, TILE_ROWS, rank, world)
-    max_rows = max(gmlrt.part_rows(h, TILE_ROWS, r, world) for r in range(world))
-    out = torch.zeros((max_rows, w, 3), dtype=torch.uint8, device=dev)  # padded so every rank gathers equal shapes
+    # padded so every rank gathers equal shapes
+    out = torch.zeros((rowtiles.padded_rows(h, TILE_ROWS, world), w, 3), dtype=torch.uint8, device=dev)
     gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         st = scene.render_into(p, out.data_ptr(), None, stream)
         if world > 1:
-            dist.gather(out, gathered, dst=0)  # the final framebuffer gather: the only collective
+            rowtiles.gather_to_rank0(out, gathered)  # the final framebuffer gather: the only collective
         return st
 
     for _ in range(args.warmup):

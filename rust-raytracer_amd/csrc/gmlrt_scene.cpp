@@ -241,9 +241,13 @@ struct Compiler {
 
   void call(const AVal& c, AStack& stack) {
     if (c.k != AVal::Closure) throw gml::GmlError("WrongType");
+    // loops are recursion in GML; one that does not end on constants would unroll for ever
+    if (++depth > 2000) throw UnsupportedSurface("surface function recurses on a data-dependent condition");
     AEnv e{c.clo->asnap, c.clo->base, {}};
     eval(e, stack, *c.clo->ast);
+    --depth;
   }
+  int depth = 0;
 
   void eval_op(gml::Op op, AStack& st) {
     using gml::Op;

@@ -1,0 +1,143 @@
+"""The C ABI: every symbol include/gmlrt.h declares is exported, the host-side entry points behave
+(no compute calls here: those need a GPU and live in test_gpu_parity.py)."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+
+def test_library_exports_every_declared_symbol(gmlrt):
+    hdr = open(os.path.join(ROOT, "include", "gmlrt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gmlrt_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(gmlrt.EXPORTS)
+    L = gmlrt.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_strerror_and_status_codes(gmlrt):
+    L = gmlrt.lib()
+    assert L.gmlrt_strerror(0) == b"ok"
+    for code in range(-9, 0):
+        assert L.gmlrt_strerror(code) not in (b"ok", b"unknown status")
+    assert L.gmlrt_strerror(-99) == b"unknown status"
+
+
+def test_row_partition(gmlrt):
+    h = 2160
+    for nparts, tile in [(1, 8), (2, 8), (3, 16), (8, 8), (7, 5)]:
+        seen = []
+        for part in range(nparts):
+            rows = gmlrt.part_row_index(h, tile, part, nparts)
+            assert len(rows) == gmlrt.part_rows(h, tile, part, nparts)
+            assert (np.diff(rows) > 0).all()
+            seen.append(rows)
+        allrows = np.sort(np.concatenate(seen))
+        assert (allrows == np.arange(h)).all()
+    # ragged last tile and more parts than tiles
+    assert gmlrt.part_rows(10, 8, 1, 2) == 2 and list(gmlrt.part_row_index(10, 8, 1, 2)) == [8, 9]
+    assert gmlrt.part_rows(10, 8, 2, 3) == 0
+    # 8 GPUs at 2160 rows: 270 tiles of 8 -> 34 or 33 tiles each
+    assert sorted(gmlrt.part_rows(2160, 8, p, 8) for p in range(8)) == [264] * 2 + [272] * 6
+
+
+@pytest.mark.parametrize("name,leaves,lights", [("spheres", 3, 1), ("chess", 261, 1), ("fractal", 586, 1),
+                                                ("cone-fractal", 66, 2), ("spotlight", 1, 3), ("house", 5, 0),
+                                                ("large", 8, 1)])
+def test_program_flattening(gmlrt, name, leaves, lights):
+    prog = gmlrt.Program(path=os.path.join(SCENES, name + ".gml"))
+    assert len(prog.calls) == 1
+    c = prog.calls[0]
+    assert c.filename == name + ".ppm"
+    hdr = struct.unpack_from("<IIQIIIIIIII", c.blob, 0)
+    assert hdr[0] == 0x54524C47 and hdr[2] == len(c.blob)
+    assert hdr[3] == leaves and hdr[4] == 2 * leaves - 1 and hdr[5] == lights
+
+
+def test_render_operands_match_the_program(gmlrt):
+    c = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0]
+    p = c.params
+    assert (p.width, p.height, p.depth, p.fov_deg) == (400, 300, 3, 60.0)
+    assert tuple(p.amb) == (0.33, 0.33, 0.33)
+    c2 = c.with_overrides(3840, 2160, 5)
+    assert (c2.params.width, c2.params.height, c2.params.depth) == (3840, 2160, 5) and p.width == 400
+
+
+def test_multiple_render_calls(gmlrt):
+    text = ('{ /v /u /face 1.0 1.0 1.0 point 1.0 0.0 1.0 } sphere /s 1.0 1.0 1.0 point /a '
+            'a [ ] s 1 90.0 8 8 "a.ppm" render a [ ] s 0.0 0.0 2.0 translate 2 60.0 16 4 "b.ppm" render')
+    prog = gmlrt.Program(text=text)
+    assert [(c.filename, c.params.width, c.params.height, c.params.depth) for c in prog.calls] == \
+        [("a.ppm", 8, 8, 1), ("b.ppm", 16, 4, 2)]
+
+
+def test_gml_errors_become_status_codes(gmlrt):
+    for text, status in [("{ 1", gmlrt.lib().gmlrt_strerror(-5)), ("1 2 addf", None), ("x", None), ("[1 2] 5 get", None)]:
+        with pytest.raises(gmlrt.GmlrtError) as e:
+            gmlrt.Program(text=text)
+        assert e.value.status == -5
+    with pytest.raises(gmlrt.GmlrtError) as e:
+        gmlrt.Program(path="/nonexistent/file.gml")
+    assert e.value.status == -7
+    # a surface the bytecode cannot express is reported as such when the scene is flattened for render
+    bad = ('{ /v /u /face 0.0 u lessf { { 1.0 } } { { 2.0 } } if apply u v point 1.0 0.0 1.0 } sphere /s '
+           '1.0 1.0 1.0 point [ ] s 1 90.0 8 8 "a.ppm" render')
+    with pytest.raises(gmlrt.GmlrtError) as e:
+        gmlrt.Program(text=bad)
+    assert e.value.status == -6
+
+
+def test_blob_validation_rejects_corruption(gmlrt):
+    L = gmlrt.lib()
+    blob = bytearray(gmlrt.Program(path=os.path.join(SCENES, "spheres.gml")).calls[0].blob)
+    h = ctypes.c_void_p()
+
+    def create(b):
+        return L.gmlrt_scene_create(bytes(b), len(b), 0, ctypes.byref(h))
+
+    assert create(blob[:40]) == -2                      # shorter than the header
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    assert create(bad) == -2                            # magic
+    bad = bytearray(blob); struct.pack_into("<I", bad, 20, 7)
+    assert create(bad) == -2                            # node count no longer 2*leaves-1
+    off_nodes = struct.unpack_from("<Q", blob, 56)[0]
+    bad = bytearray(blob); struct.pack_into("<I", bad, off_nodes, 2)
+    assert create(bad) == -2                            # leaves out of order
+    bad = bytearray(blob); struct.pack_into("<I", bad, off_nodes + 8, 0x40000003)
+    assert create(bad) == -2                            # rule 3 does not exist
+    off_leaves = struct.unpack_from("<Q", blob, 48)[0]
+    bad = bytearray(blob); struct.pack_into("<I", bad, off_leaves + 192, 9)
+    assert create(bad) == -2                            # primitive type 9
+    bad = bytearray(blob); struct.pack_into("<I", bad, off_leaves + 196, 1 << 20)
+    assert create(bad) == -2                            # surface code offset out of range
+    assert b"" != L.gmlrt_last_error()
+
+
+def test_write_ppm(gmlrt, tmp_path):
+    img = (np.arange(4 * 6 * 3) % 256).astype(np.uint8).reshape(4, 6, 3)
+    path = str(tmp_path / "t.ppm")
+    gmlrt.write_ppm(path, img)
+    data = open(path, "rb").read()
+    assert data.startswith(b"P6 6 4 255\n") and data[len(b"P6 6 4 255\n"):] == img.tobytes()
+
+
+def test_render_without_init_or_gpu_fails_loudly(gmlrt):
+    # in this container there is no GPU: init must fail with a status, never fall back to a CPU path
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = gmlrt.lib()
+    assert L.gmlrt_init(0) == -3
+    c = gmlrt.Program(path=os.path.join(SCENES, "spheres.gml")).calls[0]
+    out = np.zeros((c.params.height, c.params.width, 3), np.uint8)
+    st = gmlrt.Stats()
+    assert L.gmlrt_render(c.blob, len(c.blob), ctypes.byref(c.params), out.ctypes.data_as(ctypes.c_void_p), None,
+                          ctypes.byref(st)) == -9
+    h = ctypes.c_void_p()
+    assert L.gmlrt_scene_create(c.blob, len(c.blob), 0, ctypes.byref(h)) == -3
