@@ -46,7 +46,7 @@ const char* gmlrt_last_error(void);
  * header, then the sections at the byte offsets the header gives.  Little endian.
  */
 #define GMLRT_BLOB_MAGIC 0x54524C47u /* "GLRT" */
-#define GMLRT_BLOB_VERSION 1u
+#define GMLRT_BLOB_VERSION 2u
 
 enum gmlrt_prim_type { /* primitives.rs:328, 441, 576, 754, 924 */
   GMLRT_SPHERE = 0, GMLRT_CUBE = 1, GMLRT_CYLINDER = 2, GMLRT_CONE = 3, GMLRT_PLANE = 4
@@ -73,9 +73,26 @@ typedef struct gmlrt_leaf {
 /* CSG tree in postfix order: one 32-bit word per node.
  *   bits 31..30 = 0: leaf,     bits 29..0 = leaf index
  *   bits 31..30 = 1: operator, bits 1..0 = gmlrt_rule,
- *                    bit 2 = left operand is a leaf, bit 3 = right operand is a leaf */
+ *                    bit 2 = left operand is a leaf, bit 3 = right operand is a leaf
+ *   bits 31..30 = 2: bound (optional hint, placed BEFORE the first word of a subtree):
+ *                    bits 29..15 = index into the bounds section, bits 14..0 = number of
+ *                    program words of that subtree (nested bound words included).
+ *                    A ray that misses the bound's sphere gets an empty list for the
+ *                    subtree without visiting it.  The reference has no counterpart
+ *                    (it tests every primitive for every ray, primitives.rs:253-315);
+ *                    a bound never changes a result as long as the sphere encloses
+ *                    every point of the subtree's solid.  Bound words are not counted
+ *                    in the tree shape: n_nodes = 2*n_leaves - 1 + n_bounds. */
 #define GMLRT_NODE_LEAF(i) ((uint32_t)(i))
 #define GMLRT_NODE_OP(rule, lleaf, rleaf) (0x40000000u | (uint32_t)(rule) | ((lleaf) ? 4u : 0u) | ((rleaf) ? 8u : 0u))
+#define GMLRT_NODE_BOUND(idx, nwords) (0x80000000u | ((uint32_t)(idx) << 15) | (uint32_t)(nwords))
+#define GMLRT_BOUND_MAX 32767u /* largest index / word count a bound word can carry */
+
+/* World-space sphere enclosing the solid of one subtree. */
+typedef struct gmlrt_bound {
+  double center[3];
+  double radius;
+} gmlrt_bound;
 
 typedef struct gmlrt_light {
   uint32_t kind; /* gmlrt_light_kind */
@@ -128,14 +145,15 @@ typedef struct gmlrt_blob_header {
   uint32_t magic, version;
   uint64_t total_bytes;
   uint32_t n_leaves;
-  uint32_t n_nodes;      /* postfix words; 2*n_leaves-1 */
+  uint32_t n_nodes;      /* postfix words; 2*n_leaves-1 + n_bounds */
   uint32_t n_lights;
   uint32_t n_code_words; /* 64-bit surface instruction words */
   uint32_t n_consts;     /* 8-byte constants */
   uint32_t max_stack;    /* deepest operand stack the postfix program reaches */
   uint32_t max_events;   /* per-ray event slots the traversal can need (worst case) */
-  uint32_t reserved;
+  uint32_t n_bounds;     /* gmlrt_bound records (0 = no acceleration hints) */
   uint64_t off_leaves, off_nodes, off_lights, off_code, off_consts; /* byte offsets from the blob start */
+  uint64_t off_bounds;
 } gmlrt_blob_header;
 
 /* ------------------------------------------------------------------ render call */

@@ -138,10 +138,11 @@ __device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__
 // marks a two-event primitive list shorter than 1e-10 (it vanishes in any operator
 // whose other operand is empty, primitives.rs:295-298).
 __device__ inline Hit intersect_scene(const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes,
-                                      uint32_t n_nodes, bool active, V3 o, V3 d, double* __restrict__ evD,
+                                      const gmlrt_bound* __restrict__ bounds, uint32_t n_nodes, uint32_t n_leaves,
+                                      bool active, V3 o, V3 d, double* __restrict__ evD,
                                       uint32_t* __restrict__ evM, uint16_t* __restrict__ lens) {
   Hit h = {false, 0.0, 0u};
-  if (n_nodes == 1) {
+  if (n_leaves == 1) {
     // The root is a bare primitive: its raw list is what trace sees, a lone Exit included.
     double scale; V3 rd, rp;
     to_object(leaves->inv_m, o, d, scale, rd, rp);
@@ -158,6 +159,23 @@ __device__ inline Hit intersect_scene(const gmlrt_leaf* __restrict__ leaves, con
   const int tid = threadIdx.x;
   for (uint32_t pc = 0; pc < n_nodes; pc++) {
     const uint32_t word = nodes[pc];
+    if ((word >> 30) == 2) {
+      // Bounding sphere in front of a subtree: if no lane's ray comes near it, every
+      // list below is empty, so is the subtree's: push that and jump over its words.
+      const gmlrt_bound* __restrict__ B = bounds + ((word >> 15) & 0x7FFFu);
+      const V3 oc = {B->center[0] - o.x, B->center[1] - o.y, B->center[2] - o.z};
+      const double tca = vdot(oc, d);
+      const V3 perp = vsub(oc, vmul(d, tca));
+      const double r2 = B->radius * B->radius;
+      // any NaN compares false and keeps the subtree
+      const bool miss = !active || vdot(perp, perp) > r2 || (tca < 0.0 && vdot(oc, oc) > r2);
+      if (!__ballot(!miss)) {
+        lens[level * kBlock + tid] = 0;
+        level++;
+        pc += word & 0x7FFFu;
+      }
+      continue;
+    }
     if ((word >> 30) == 0) {
       const gmlrt_leaf* __restrict__ L = leaves + (word & 0x3FFFFFFFu);
       double scale; V3 rd, rp;
@@ -433,7 +451,8 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
 #endif
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
-    const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const KArgs A) {
+    const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
+    const KArgs A) {
   extern __shared__ uint16_t lens[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -452,52 +471,61 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   S.li = 0;
   S.n_shadow = S.n_reflect = S.n_hits = 0;
   uint32_t n_primary = 0;
-  bool more = true;   // wave-uniform: pixel slots left to hand out
+  // Pixels are handed out in 8x8 tiles.  A wave owns one tile at a time and feeds
+  // its idle lanes from it, so the rays a wave traverses together stay close on
+  // screen (that is what lets a whole wave skip a bounded subtree); a new tile comes
+  // from a global counter when the current one is used up.  All three are wave-uniform.
+  bool more = true;        // the global counter still has tiles
+  uint32_t tile_base = 0;  // next slot of the wave's tile
+  uint32_t tile_left = 0;  // slots of it not handed out yet
 
   for (;;) {
     // ---- hand new pixels to idle lanes
-    if (more) {
-      const unsigned long long idle = __ballot(S.kind == kIdle);
-      if (idle) {
-        const uint32_t cnt = (uint32_t)__popcll(idle);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.next_slot, cnt);
-        base = (uint32_t)__shfl((int)base, 0);
-        if (S.kind == kIdle) {
-          const uint32_t slot = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-          if (slot < A.n_slots) {
-            // slot -> 8x8 tile -> pixel of this partition's packed rows
-            const uint32_t tile = slot >> 6, in = slot & 63u;
-            const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
-            const uint32_t yl = (tile / A.tiles_x) * 8u + (in >> 3);
-            if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
-              uint32_t y = yl;
-              if (A.nparts > 1) {
-                const uint32_t k = yl / (uint32_t)A.tile_rows;
-                y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yl % (uint32_t)A.tile_rows;
-              }
-              // raytracer.rs:138-142
-              const double xf = (double)x, yf = (double)y;
-              V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
-              S.o = {0.0, 0.0, -1.0};
-              S.d = vnormalize(dir);
-              S.kind = kView;
-              S.level = 0;
-              S.pix = yl * (uint32_t)A.w + x;
-              n_primary++;
-            }
-          }
-        }
-        if (base + cnt >= A.n_slots) more = false;
+    unsigned long long idle = __ballot(S.kind == kIdle);
+    while (idle && (tile_left || more)) {
+      if (tile_left == 0) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(A.next_slot, 64u);
+        t = (uint32_t)__shfl((int)t, 0);
+        if (t >= A.n_slots) { more = false; break; }
+        tile_base = t;
+        tile_left = 64u;
       }
+      const uint32_t want = (uint32_t)__popcll(idle);
+      const uint32_t take = want < tile_left ? want : tile_left;
+      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (S.kind == kIdle && rank < take) {
+        // slot -> 8x8 tile -> pixel of this partition's packed rows
+        const uint32_t slot = tile_base + rank;
+        const uint32_t tile = slot >> 6, in = slot & 63u;
+        const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
+        const uint32_t yl = (tile / A.tiles_x) * 8u + (in >> 3);
+        if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
+          uint32_t y = yl;
+          if (A.nparts > 1) {
+            const uint32_t k = yl / (uint32_t)A.tile_rows;
+            y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yl % (uint32_t)A.tile_rows;
+          }
+          // raytracer.rs:138-142
+          const double xf = (double)x, yf = (double)y;
+          V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
+          S.o = {0.0, 0.0, -1.0};
+          S.d = vnormalize(dir);
+          S.kind = kView;
+          S.level = 0;
+          S.pix = yl * (uint32_t)A.w + x;
+          n_primary++;
+        }
+      }
+      tile_base += take;
+      tile_left -= take;
+      idle = __ballot(S.kind == kIdle);  // lanes that drew a padding slot are still idle
     }
-    if (!__ballot(S.kind != kIdle)) {
-      if (!more) break;
-      continue;
-    }
+    if (!__ballot(S.kind != kIdle)) break;  // nothing in flight and nothing left to hand out
 
     // ---- one scene traversal for whatever ray each lane holds
-    const Hit h = intersect_scene(leaves, nodes, A.n_nodes, S.kind != kIdle, S.o, S.d, evD, evM, lens);
+    const Hit h = intersect_scene(leaves, nodes, bounds, A.n_nodes, A.n_leaves, S.kind != kIdle, S.o, S.d, evD, evM,
+                                  lens);
     // ---- then the per-ray bookkeeping, out of line
     if (S.kind != kIdle) S = after_traversal(S, h, P, A, ctx);
   }
@@ -592,6 +620,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   const gmlrt_light* d_lights = (const gmlrt_light*)(base + H.off_lights);
   const uint64_t* d_code = (const uint64_t*)(base + H.off_code);
   const uint64_t* d_consts = (const uint64_t*)(base + H.off_consts);
+  const gmlrt_bound* d_bounds = (const gmlrt_bound*)(base + H.off_bounds);
 
   KArgs A;
   std::memset(&A, 0, sizeof(A));
@@ -683,7 +712,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                     d_code, d_consts, A);
+                     d_code, d_consts, d_bounds, A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   unsigned long long counts[4] = {0, 0, 0, 0};

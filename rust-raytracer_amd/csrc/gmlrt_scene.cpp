@@ -556,20 +556,115 @@ struct Flattener : gml::TreeVisitor {
     L.surf_code = it->second.first;
     L.surf_const = it->second.second;
     if (leaves.size() >= (1u << 20)) throw gml::GmlError("scene has more than 2^20 leaves");
-    nodes.push_back(GMLRT_NODE_LEAF(leaves.size()));
+    FNode n;
+    n.leaf = (int)leaves.size();
+    n.n_leaves = 1;
+    n.bnd = leaf_bound(prim, t);
     leaves.push_back(L);
-    ostack.emplace_back(true, 2);
-    sp += 2;
-    max_events = std::max(max_events, sp);
-    max_stack = std::max(max_stack, ostack.size());
+    tstack.push_back((int)tree.size());
+    tree.push_back(n);
   }
   void op(gml::Rule rule) override {
-    auto b = ostack.back(); ostack.pop_back();
-    auto a = ostack.back(); ostack.pop_back();
-    nodes.push_back(GMLRT_NODE_OP((uint32_t)rule, a.first, b.first));
-    // the merge writes its output above both operands before moving it down
-    max_events = std::max(max_events, sp + a.second + b.second);
-    ostack.emplace_back(false, a.second + b.second);
+    FNode n;
+    n.b = tstack.back(); tstack.pop_back();
+    n.a = tstack.back(); tstack.pop_back();
+    n.rule = rule;
+    n.n_leaves = tree[(size_t)n.a].n_leaves + tree[(size_t)n.b].n_leaves;
+    const Bound &ba = tree[(size_t)n.a].bnd, &bb = tree[(size_t)n.b].bnd;
+    // a point of the result lies in A or B (union), in A and B (intersect), in A (difference)
+    if (rule == gml::Rule::Union) n.bnd = sphere_union(ba, bb);
+    else if (rule == gml::Rule::Intersect) n.bnd = (!bb.finite || (ba.finite && ba.r <= bb.r)) ? ba : bb;
+    else n.bnd = ba;
+    tstack.push_back((int)tree.size());
+    tree.push_back(n);
+  }
+
+  // ---- bounding spheres (acceleration hints; see GMLRT_NODE_BOUND in include/gmlrt.h)
+  struct Bound { bool finite = false; double c[3] = {0, 0, 0}; double r = 0; };
+  struct FNode { int a = -1, b = -1, leaf = -1; gml::Rule rule = gml::Rule::Union; uint32_t n_leaves = 0; Bound bnd; };
+  std::vector<FNode> tree;
+  std::vector<int> tstack;
+  std::vector<gmlrt_bound> bounds;
+
+  static Bound leaf_bound(gml::PrimType prim, const gml::Transform& t) {
+    Bound b;
+    double lc[3] = {0, 0, 0}, lr = 1.0;
+    switch (prim) {
+      case gml::PrimType::Sphere: break;                                             // |p| <= 1
+      case gml::PrimType::Cube: lc[0] = lc[1] = lc[2] = 0.5; lr = 0.8660254037844387; break;  // [0,1]^3
+      case gml::PrimType::Cylinder: lc[1] = 0.5; lr = 1.118033988749895; break;      // r 1, 0 <= y <= 1
+      case gml::PrimType::Cone: lc[1] = 1.0; lr = 1.0; break;                        // apex 0, rim radius 1 at y=1
+      default: return b;                                                              // half-space: unbounded
+    }
+    const double (*M)[4] = t.m.m;
+    // largest stretch of the linear part: lambda_max(M^T M) <= its largest absolute row sum
+    double s2 = 0.0;
+    for (int i = 0; i < 3; i++) {
+      double row = 0.0;
+      for (int j = 0; j < 3; j++) {
+        double e = 0.0;
+        for (int k = 0; k < 3; k++) e += M[k][i] * M[k][j];
+        row += std::fabs(e);
+      }
+      s2 = std::max(s2, row);
+    }
+    for (int i = 0; i < 3; i++) b.c[i] = M[i][0] * lc[0] + M[i][1] * lc[1] + M[i][2] * lc[2] + M[i][3];
+    b.r = lr * std::sqrt(s2) * (1.0 + 1e-6) + 1e-9;
+    b.finite = std::isfinite(b.r) && std::isfinite(b.c[0]) && std::isfinite(b.c[1]) && std::isfinite(b.c[2]);
+    return b;
+  }
+  static Bound sphere_union(const Bound& p, const Bound& q) {
+    Bound u;
+    if (!p.finite || !q.finite) return u;
+    const double d[3] = {q.c[0] - p.c[0], q.c[1] - p.c[1], q.c[2] - p.c[2]};
+    const double dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (dist + q.r <= p.r) return p;
+    if (dist + p.r <= q.r) return q;
+    u.r = 0.5 * (dist + p.r + q.r);
+    const double f = dist > 0.0 ? (u.r - p.r) / dist : 0.0;
+    for (int i = 0; i < 3; i++) u.c[i] = p.c[i] + d[i] * f;
+    u.r = u.r * (1.0 + 1e-9) + 1e-12;
+    u.finite = std::isfinite(u.r);
+    return u;
+  }
+
+  // Emits the postfix program of subtree `n`.  A bound word goes in front of it when
+  // its sphere is finite and clearly tighter than the nearest enclosing emitted one
+  // (testing nested spheres of almost the same size costs more than it saves).
+  void emit(int ni, double enclosing_r) {
+    const FNode& n = tree[(size_t)ni];
+    const bool is_leaf = n.leaf >= 0;
+    const uint64_t worst_words = 2ull * (2ull * n.n_leaves - 1ull);
+    bool want = n.bnd.finite && bounds.size() < GMLRT_BOUND_MAX && worst_words <= GMLRT_BOUND_MAX;
+    if (want && std::isfinite(enclosing_r)) want = n.bnd.r <= (is_leaf ? 0.5 : 0.7) * enclosing_r;
+    size_t at = 0;
+    if (want) {
+      at = nodes.size();
+      nodes.push_back(0);
+      gmlrt_bound g;
+      for (int i = 0; i < 3; i++) g.center[i] = n.bnd.c[i];
+      g.radius = n.bnd.r;
+      bounds.push_back(g);
+    }
+    const size_t my_bound = bounds.size() - 1;
+    const double inner_r = want ? n.bnd.r : enclosing_r;
+    if (is_leaf) {
+      nodes.push_back(GMLRT_NODE_LEAF(n.leaf));
+      ostack.emplace_back(true, 2);
+      sp += 2;
+      max_events = std::max(max_events, sp);
+      max_stack = std::max(max_stack, ostack.size());
+    } else {
+      emit(n.a, inner_r);
+      emit(n.b, inner_r);
+      auto b = ostack.back(); ostack.pop_back();
+      auto a = ostack.back(); ostack.pop_back();
+      nodes.push_back(GMLRT_NODE_OP((uint32_t)n.rule, a.first, b.first));
+      // the merge writes its output above both operands before moving it down
+      max_events = std::max(max_events, sp + a.second + b.second);
+      ostack.emplace_back(false, a.second + b.second);
+    }
+    if (want) nodes[at] = GMLRT_NODE_BOUND(my_bound, nodes.size() - at - 1);
   }
 };
 
@@ -586,6 +681,7 @@ void append(std::vector<uint8_t>& blob, uint64_t* off, const std::vector<T>& v) 
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc) {
   Flattener f;
   gml::walk_postfix(rc.scene, f);
+  f.emit(f.tstack.back(), std::numeric_limits<double>::infinity());
   std::vector<gmlrt_light> lights;
   for (auto& l : rc.lights) {
     gmlrt_light g;
@@ -608,12 +704,14 @@ std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc) {
   h.max_stack = (uint32_t)f.max_stack;
   if (f.max_events > 0xFFFFFFFFull) throw gml::GmlError("scene too large");
   h.max_events = (uint32_t)f.max_events;
+  h.n_bounds = (uint32_t)f.bounds.size();
   std::vector<uint8_t> blob(sizeof(h), 0);
   append(blob, &h.off_leaves, f.leaves);
   append(blob, &h.off_nodes, f.nodes);
   append(blob, &h.off_lights, lights);
   append(blob, &h.off_code, f.code);
   append(blob, &h.off_consts, f.consts);
+  append(blob, &h.off_bounds, f.bounds);
   while (blob.size() % 16) blob.push_back(0);
   h.total_bytes = blob.size();
   std::memcpy(blob.data(), &h, sizeof(h));
@@ -629,7 +727,8 @@ std::string validate_blob(const void* blob, size_t bytes) {
   if (h.version != GMLRT_BLOB_VERSION) return "unsupported blob version";
   if (h.total_bytes != bytes) return "total_bytes does not match the buffer size";
   if (h.n_leaves == 0 || h.n_leaves > (1u << 20)) return "leaf count out of range";
-  if (h.n_nodes != 2 * h.n_leaves - 1) return "node count is not 2*leaves-1";
+  if (h.n_bounds > GMLRT_BOUND_MAX + 1u) return "too many bounds";
+  if (h.n_nodes != 2 * h.n_leaves - 1 + h.n_bounds) return "node count is not 2*leaves-1+bounds";
   auto section_ok = [&](uint64_t off, uint64_t count, uint64_t elem) {
     return off % 8 == 0 && off >= sizeof(h) && off <= bytes && count * elem <= bytes - off;
   };
@@ -638,7 +737,16 @@ std::string validate_blob(const void* blob, size_t bytes) {
   if (!section_ok(h.off_lights, h.n_lights, sizeof(gmlrt_light))) return "light section out of bounds";
   if (!section_ok(h.off_code, h.n_code_words, 8)) return "code section out of bounds";
   if (!section_ok(h.off_consts, h.n_consts, 8)) return "constant section out of bounds";
+  if (!section_ok(h.off_bounds, h.n_bounds, sizeof(gmlrt_bound))) return "bounds section out of bounds";
   const uint8_t* base = (const uint8_t*)blob;
+  const gmlrt_bound* bnds = (const gmlrt_bound*)(base + h.off_bounds);
+  for (uint32_t i = 0; i < h.n_bounds; i++)
+    if (!(bnds[i].radius >= 0.0) || !std::isfinite(bnds[i].radius) || !std::isfinite(bnds[i].center[0]) ||
+        !std::isfinite(bnds[i].center[1]) || !std::isfinite(bnds[i].center[2]))
+      return "bound is not a finite sphere";
+  // open bound words: (index of the first word after the subtree, operand-stack depth when it opened)
+  std::vector<std::pair<uint32_t, size_t>> open_bounds;
+  uint32_t bounds_seen = 0;
   const gmlrt_leaf* leaves = (const gmlrt_leaf*)(base + h.off_leaves);
   const uint32_t* nodes = (const uint32_t*)(base + h.off_nodes);
   const uint64_t* code = (const uint64_t*)(base + h.off_code);
@@ -662,16 +770,33 @@ std::string validate_blob(const void* blob, size_t bytes) {
     } else if (kind == 1) {
       if ((w & 3u) > 2u || (w & 0x3FFFFFF0u) != 0) return "bad operator word";
       if (st.size() < 2) return "postfix program underflows its stack";
+      if (!open_bounds.empty() && st.size() < open_bounds.back().second + 2)
+        return "bound does not cover exactly one subtree";
       auto b = st.back(); st.pop_back();
       auto a = st.back(); st.pop_back();
       if (((w >> 2) & 1u) != (a.first ? 1u : 0u) || ((w >> 3) & 1u) != (b.first ? 1u : 0u))
         return "operator leaf-operand flags do not match the tree";
       max_events = std::max(max_events, sp + a.second + b.second);
       st.emplace_back(false, a.second + b.second);
+    } else if (kind == 2) {
+      // the words a bound covers must be exactly one complete subtree: the kernel
+      // replaces them by one empty list and continues right after them
+      const uint32_t idx = (w >> 15) & 0x7FFFu, nwords = w & 0x7FFFu;
+      if (idx >= h.n_bounds) return "bound index out of range";
+      if (nwords == 0 || (uint64_t)i + 1 + nwords > h.n_nodes) return "bound covers words past the program";
+      if (!open_bounds.empty() && i + 1 + nwords > open_bounds.back().first) return "bound crosses an enclosing bound";
+      open_bounds.emplace_back(i + 1 + nwords, st.size());
+      bounds_seen++;
+      continue;
     } else {
       return "bad node word";
     }
+    while (!open_bounds.empty() && open_bounds.back().first == i + 1) {
+      if (st.size() != open_bounds.back().second + 1) return "bound does not cover exactly one subtree";
+      open_bounds.pop_back();
+    }
   }
+  if (!open_bounds.empty() || bounds_seen != h.n_bounds) return "bound words do not match the bounds section";
   if (st.size() != 1 || next_leaf != h.n_leaves) return "postfix program does not reduce to one root";
   if (h.max_stack < max_stack) return "max_stack too small";
   if (h.max_events < max_events) return "max_events too small";

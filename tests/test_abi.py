@@ -57,7 +57,12 @@ def test_program_flattening(gmlrt, name, leaves, lights):
     assert c.filename == name + ".ppm"
     hdr = struct.unpack_from("<IIQIIIIIIII", c.blob, 0)
     assert hdr[0] == 0x54524C47 and hdr[2] == len(c.blob)
-    assert hdr[3] == leaves and hdr[4] == 2 * leaves - 1 and hdr[5] == lights
+    n_bounds = hdr[10]
+    assert hdr[3] == leaves and hdr[4] == 2 * leaves - 1 + n_bounds and hdr[5] == lights
+    # the program words: one per leaf, one per operator, one per bound
+    off_nodes = struct.unpack_from("<Q", c.blob, 56)[0]
+    kinds = [w >> 30 for w in struct.unpack_from("<%dI" % hdr[4], c.blob, off_nodes)]
+    assert (kinds.count(0), kinds.count(1), kinds.count(2)) == (leaves, leaves - 1, n_bounds)
 
 
 def test_render_operands_match_the_program(gmlrt):
@@ -104,8 +109,15 @@ def test_blob_validation_rejects_corruption(gmlrt):
     assert create(blob[:40]) == -2                      # shorter than the header
     bad = bytearray(blob); bad[0] ^= 0xFF
     assert create(bad) == -2                            # magic
-    bad = bytearray(blob); struct.pack_into("<I", bad, 20, 7)
-    assert create(bad) == -2                            # node count no longer 2*leaves-1
+    bad = bytearray(blob); struct.pack_into("<I", bad, 20, 9)
+    assert create(bad) == -2                            # node count no longer 2*leaves-1+bounds
+    off_nodes = struct.unpack_from("<Q", blob, 56)[0]
+    assert struct.unpack_from("<I", blob, off_nodes)[0] == 0x80000001   # bound 0 in front of the one-word subtree "leaf 0"
+    bad = bytearray(blob); struct.pack_into("<I", bad, off_nodes, 0x80000002)
+    assert create(bad) == -2                            # two words after it are not one complete subtree
+    off_bounds = struct.unpack_from("<Q", blob, 88)[0]
+    bad = bytearray(blob); struct.pack_into("<d", bad, off_bounds + 24, float("inf"))
+    assert create(bad) == -2                            # bound radius must be finite
     off_nodes = struct.unpack_from("<Q", blob, 56)[0]
     bad = bytearray(blob); struct.pack_into("<I", bad, off_nodes, 2)
     assert create(bad) == -2                            # leaves out of order
