@@ -7,7 +7,35 @@
 
 #include "../../include/gmlrt.h"
 
+#include <vector>
+
 namespace gmlrt {
+
+// Records of the derived traversal program (gmlrt_program.cpp): a byte stream of
+// 16-byte-aligned records, operands inline.  `kind` = record kind in bits 3..0,
+// kRecFlag in bit 8, a leaf's primitive type in bits 18..16.
+constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4;
+constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
+struct ProgBound {   // 48 bytes
+  uint32_t kind;
+  uint32_t skip_to;  // byte offset of the first record after the bounded subtree
+  double center[3];
+  double radius2;
+  uint64_t pad;
+};
+struct ProgLeaf {    // 112 bytes
+  uint32_t kind;
+  uint32_t leaf;     // index into the blob's leaf section
+  double inv_m[12];
+  uint64_t pad;
+};
+struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags), take, end
+  uint32_t kind;
+  uint32_t arg;
+  uint64_t pad;
+};
+static_assert(sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
+std::vector<uint8_t> derive_stream_program(const void* blob);
 
 // Device-resident copy of one scene blob plus the per-device scratch the render
 // kernel needs (per-ray event stacks, shading contexts, counters).
@@ -15,6 +43,8 @@ struct DeviceScene {
   int device = -1;
   void* d_blob = nullptr;
   size_t blob_bytes = 0;
+  void* d_prog = nullptr;       // derived program (record stream)
+  uint32_t n_prog = 0;          // its size in bytes
   gmlrt_blob_header hdr{};
   // workspace, grown on demand and kept for the life of the handle
   void* d_ev_dist = nullptr;

@@ -55,6 +55,7 @@ struct ScenePtrs {
 
 struct KArgs {
   uint32_t n_leaves, n_nodes, n_lights, max_stack;
+  uint32_t n_prog;       // words of the derived program
   double amb[3];
   double c_x, c_y, pw;  // camera, raytracer.rs:131-136
   int32_t depth;
@@ -72,10 +73,36 @@ struct KArgs {
   uint32_t ctx_fields;
   unsigned int* next_slot;
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
+  unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
 };
 
+// What the out-of-line per-ray code needs of the launch parameters.  It lives in
+// device memory and is reached through a pointer: a by-value copy would travel
+// through the stack (scratch memory) at every call.
+struct ShadeArgs {
+  double amb[3];
+  int32_t depth;
+  uint32_t n_lights;
+  uint32_t ctx_fields;
+  uint32_t pad;
+  uint8_t* rgb8;
+  double* rgbf;
+};
+
+// Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
+// where the cycles went.  Never part of the shipped library; numbers from it are
+// shares, not timings.
+struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes; };
+#ifdef GMLRT_DIAG
+#define DIAG(x) x
+#else
+#define DIAG(x)
+#endif
+
 // ---------------------------------------------------------------- CSG traversal
-struct Hit { bool any; double dist; uint32_t meta; };
+// First element of the root list.  redo: the shortcut traversal met a case it does
+// not cover and this lane must be traced again with the full list algorithm.
+struct Hit { bool any; double dist; uint32_t meta; bool redo; };
 
 __device__ inline bool csg_rule(uint32_t rule, bool a, bool b) {
   return rule == GMLRT_UNION ? (a || b) : rule == GMLRT_INTERSECT ? (a && b) : (a && !b);
@@ -132,16 +159,18 @@ __device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__
   return k;
 }
 
-// Node::intersect of the whole scene for one ray per lane; returns the first
-// element of the root list (all that raytracer.rs:52-58, 74-79 look at).
+// Node::intersect of the whole scene for one ray per lane, every operator evaluated
+// with full lists; returns the first element of the root list (all that
+// raytracer.rs:52-58, 74-79 look at).  This is the complete algorithm; the kernel
+// normally runs intersect_first below and comes here only for the rare ray it flags.
 // `lens` holds, per operand-stack level and lane, the length of that list; bit 15
 // marks a two-event primitive list shorter than 1e-10 (it vanishes in any operator
 // whose other operand is empty, primitives.rs:295-298).
-__device__ inline Hit intersect_scene(const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes,
-                                      const gmlrt_bound* __restrict__ bounds, uint32_t n_nodes, uint32_t n_leaves,
-                                      bool active, V3 o, V3 d, double* __restrict__ evD,
-                                      uint32_t* __restrict__ evM, uint16_t* __restrict__ lens) {
-  Hit h = {false, 0.0, 0u};
+__device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes,
+                                              const gmlrt_bound* __restrict__ bounds, uint32_t n_nodes,
+                                              uint32_t n_leaves, bool active, V3 o, V3 d, double* __restrict__ evD,
+                                              uint32_t* __restrict__ evM, uint16_t* __restrict__ lens) {
+  Hit h = {false, 0.0, 0u, false};
   if (n_leaves == 1) {
     // The root is a bare primitive: its raw list is what trace sees, a lone Exit included.
     double scale; V3 rd, rp;
@@ -235,6 +264,8 @@ __device__ inline Hit intersect_scene(const gmlrt_leaf* __restrict__ leaves, con
   return h;
 }
 
+#include "gmlrt_traverse.hpp"
+
 // ---------------------------------------------------------------- lights (lights.rs:42-120)
 __device__ inline void light_direction(const gmlrt_light& l, V3 pos, V3& dir, bool& has_dist, double& dist) {
   if (l.kind == GMLRT_LIGHT_DIRECTIONAL) {
@@ -277,25 +308,31 @@ __device__ inline void ctx_set3(double* ctx, int f, V3 v) { CTX(f) = v.x; CTX(f 
 enum { F_POS = 0, F_NRM = 3, F_SC = 6, F_KD = 9, F_KS = 10, F_N = 11, F_C = 12, F_DIFF = 15, F_SPEC = 18,
        F_RPOS = 21, F_RDIR = 24 };
 
-// What a lane carries from one traversal to the next.
+// What a lane carries from one traversal to the next.  Kept to 56 bytes so that it
+// travels to and from the out-of-line code in registers (a larger struct would be
+// passed through the stack, i.e. scratch memory).
 struct LaneState {
-  V3 o, d;        // ray to traverse
-  int kind;       // RayKind
-  uint32_t pix;   // output index (row-in-partition * w + x)
-  int level;      // bounce level of the current view ray
-  uint32_t li;    // light being tested
-  uint32_t n_shadow, n_reflect, n_hits;
+  V3 o, d;       // ray to traverse
+  uint32_t pix;  // output index (row-in-partition * w + x)
+  uint32_t st;   // bits 1..0 RayKind, 12..2 bounce level, 23..13 light being tested,
+                 // 24 / 25 / 26: after_traversal spawned a shadow ray / a bounce / shaded a hit
 };
+constexpr uint32_t kStShadow = 1u << 24, kStReflect = 1u << 25, kStHit = 1u << 26;
+__device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 
 // Everything trace() does around its intersect calls (raytracer.rs:53-110), cut at
 // those calls: consumes the traversal result of the ray the lane holds and leaves
 // either the next ray to traverse in S or an idle lane with its pixel written.
-__device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, const ScenePtrs P, const KArgs A,
+__device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, const ScenePtrs P, const ShadeArgs* __restrict__ SA,
                                                   double* __restrict__ ctx) {
+  int kind = st_kind(S.st);
+  int level = (int)((S.st >> 2) & 0x7FFu);
+  uint32_t li = (S.st >> 13) & 0x7FFu;
+  uint32_t events = 0;
   bool advance = false, finish = false;
-  V3 C = {0.0, 0.0, 0.0};  // value of trace() at S.level when finish is set
+  V3 C = {0.0, 0.0, 0.0};  // value of trace() at level when finish is set
 
-  if (S.kind == kView) {
+  if (kind == kView) {
     if (!h.any || (h.meta & kCurExit)) {
       finish = true;  // raytracer.rs:55-57, 108-110
     } else {
@@ -324,14 +361,14 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
           if (mycode == cur) {
             // the bytecode registers live in the lane's context record, after the bounce stack
             surface_vm(P.code + cur, kc, (int64_t)face, u, v, s6,
-                       (uint64_t*)(ctx + (size_t)(A.ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), kWave);
+                       (uint64_t*)(ctx + (size_t)(SA->ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), kWave);
             pending = false;
           }
         }
       }
       const V3 sc = {s6[0], s6[1], s6[2]};
       const double kd = s6[3], ks = s6[4], sn = s6[5];
-      const V3 c = vmul(vcmul({A.amb[0], A.amb[1], A.amb[2]}, sc), kd);  // get_ambient
+      const V3 c = vmul(vcmul({SA->amb[0], SA->amb[1], SA->amb[2]}, sc), kd);  // get_ambient
       const double* m = L->m;
       const V3 pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3],
                       m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
@@ -351,13 +388,13 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
       ctx_set3(ctx, F_SPEC, {0.0, 0.0, 0.0});
       ctx_set3(ctx, F_RPOS, S.o);
       ctx_set3(ctx, F_RDIR, S.d);
-      S.li = 0;
-      S.n_hits++;
+      li = 0;
+      events |= kStHit;
       advance = true;
     }
-  } else if (S.kind == kShadow) {
+  } else if (kind == kShadow) {
     // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
-    const gmlrt_light& l = P.lights[S.li];
+    const gmlrt_light& l = P.lights[li];
     const V3 pos = ctx_get3(ctx, F_POS);
     V3 ldir; bool has_ld; double ld;
     light_direction(l, pos, ldir, has_ld, ld);
@@ -379,7 +416,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
         else ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), {0.0, 0.0, 0.0}));
       }
     }
-    S.li++;
+    li++;
     advance = true;
   }
 
@@ -388,18 +425,18 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
     const V3 pos = ctx_get3(ctx, F_POS);
     const V3 normal = ctx_get3(ctx, F_NRM);
     bool spawned = false;
-    while (S.li < A.n_lights) {
+    while (li < SA->n_lights) {
       V3 ldir; bool has_ld; double ld;
-      light_direction(P.lights[S.li], pos, ldir, has_ld, ld);
+      light_direction(P.lights[li], pos, ldir, has_ld, ld);
       if (vdot(normal, ldir) > 0.0) {
         S.o = vadd(pos, vmul(ldir, 1e-7));
         S.d = ldir;
-        S.kind = kShadow;
-        S.n_shadow++;
+        kind = kShadow;
+        events |= kStShadow;
         spawned = true;
         break;
       }
-      S.li++;
+      li++;
     }
     if (!spawned) {
       // ---- raytracer.rs:96-107
@@ -407,19 +444,19 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
       const V3 diff = vmul(ctx_get3(ctx, F_DIFF), kd);
       const V3 spec = vmul(ctx_get3(ctx, F_SPEC), ks);
       const V3 c = vadd(ctx_get3(ctx, F_C), vadd(diff, spec));
-      if (ks > 0.0 && (A.depth - S.level) > 0) {
+      if (ks > 0.0 && (SA->depth - level) > 0) {
         const V3 raydir = ctx_get3(ctx, F_RDIR);
         const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
         // park (c, sc, ks) until the bounce below returns
-        const int f = kCtxFixed + S.level * kCtxPerLevel;
+        const int f = kCtxFixed + level * kCtxPerLevel;
         ctx_set3(ctx, f, c);
         ctx_set3(ctx, f + 3, ctx_get3(ctx, F_SC));
         CTX(f + 6) = ks;
         S.o = vadd(pos, vmul(refl, 1e-7));
         S.d = refl;
-        S.kind = kView;
-        S.level++;
-        S.n_reflect++;
+        kind = kView;
+        level++;
+        events |= kStReflect;
       } else {
         C = c;
         finish = true;
@@ -429,7 +466,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
 
   if (finish) {
     // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
-    for (int lv = S.level - 1; lv >= 0; lv--) {
+    for (int lv = level - 1; lv >= 0; lv--) {
       const int f = kCtxFixed + lv * kCtxPerLevel;
       const V3 c = ctx_get3(ctx, f);
       const V3 sc = ctx_get3(ctx, f + 3);
@@ -437,22 +474,23 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, cons
       C = vadd(c, vmul(vcmul(C, sc), ks));
     }
     const size_t oidx = (size_t)S.pix * 3;
-    A.rgb8[oidx] = quantise(C.x);
-    A.rgb8[oidx + 1] = quantise(C.y);
-    A.rgb8[oidx + 2] = quantise(C.z);
-    if (A.rgbf) { A.rgbf[oidx] = C.x; A.rgbf[oidx + 1] = C.y; A.rgbf[oidx + 2] = C.z; }
-    S.kind = kIdle;
+    SA->rgb8[oidx] = quantise(C.x);
+    SA->rgb8[oidx + 1] = quantise(C.y);
+    SA->rgb8[oidx + 2] = quantise(C.z);
+    if (SA->rgbf) { SA->rgbf[oidx] = C.x; SA->rgbf[oidx + 1] = C.y; SA->rgbf[oidx + 2] = C.z; }
+    kind = kIdle;
   }
+  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | events;
   return S;
 }
 
 #ifndef GMLRT_WAVES_PER_SIMD
-#define GMLRT_WAVES_PER_SIMD 6  // measured on chess 4K: 3 -> 616, 4 -> 693, 5 -> 731, 6 -> 749, 8 -> 454 Mrays/s
+#define GMLRT_WAVES_PER_SIMD 4  // measured on chess 4K depth 5: 3 -> 1796, 4 -> 1955, 5 -> 1655, 6 -> 1794 Mrays/s
 #endif
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
-    const KArgs A) {
+    const uint8_t* __restrict__ prog, const ShadeArgs* __restrict__ shade_args, const KArgs A) {
   extern __shared__ uint16_t lens[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -465,12 +503,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   LaneState S;
   S.o = {0, 0, 0};
   S.d = {0, 0, 1};
-  S.kind = kIdle;
   S.pix = 0;
-  S.level = 0;
-  S.li = 0;
-  S.n_shadow = S.n_reflect = S.n_hits = 0;
-  uint32_t n_primary = 0;
+  S.st = kIdle;
+  uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
   // Pixels are handed out in 8x8 tiles.  A wave owns one tile at a time and feeds
   // its idle lanes from it, so the rays a wave traverses together stay close on
   // screen (that is what lets a whole wave skip a bounded subtree); a new tile comes
@@ -478,10 +513,12 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   bool more = true;        // the global counter still has tiles
   uint32_t tile_base = 0;  // next slot of the wave's tile
   uint32_t tile_left = 0;  // slots of it not handed out yet
+  Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  DIAG(unsigned long long t0 = __builtin_readcyclecounter();)
 
   for (;;) {
     // ---- hand new pixels to idle lanes
-    unsigned long long idle = __ballot(S.kind == kIdle);
+    unsigned long long idle = __ballot(st_kind(S.st) == kIdle);
     while (idle && (tile_left || more)) {
       if (tile_left == 0) {
         uint32_t t = 0;
@@ -494,7 +531,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       const uint32_t want = (uint32_t)__popcll(idle);
       const uint32_t take = want < tile_left ? want : tile_left;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-      if (S.kind == kIdle && rank < take) {
+      if (st_kind(S.st) == kIdle && rank < take) {
         // slot -> 8x8 tile -> pixel of this partition's packed rows
         const uint32_t slot = tile_base + rank;
         const uint32_t tile = slot >> 6, in = slot & 63u;
@@ -511,27 +548,40 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
           S.o = {0.0, 0.0, -1.0};
           S.d = vnormalize(dir);
-          S.kind = kView;
-          S.level = 0;
+          S.st = kView;  // level 0
           S.pix = yl * (uint32_t)A.w + x;
           n_primary++;
         }
       }
       tile_base += take;
       tile_left -= take;
-      idle = __ballot(S.kind == kIdle);  // lanes that drew a padding slot are still idle
+      idle = __ballot(st_kind(S.st) == kIdle);  // lanes that drew a padding slot are still idle
     }
-    if (!__ballot(S.kind != kIdle)) break;  // nothing in flight and nothing left to hand out
+    if (!__ballot(st_kind(S.st) != kIdle)) break;  // nothing in flight and nothing left to hand out
+    DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
+         dg.lanes += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
 
     // ---- one scene traversal for whatever ray each lane holds
-    const Hit h = intersect_scene(leaves, nodes, bounds, A.n_nodes, A.n_leaves, S.kind != kIdle, S.o, S.d, evD, evM,
-                                  lens);
+    Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, evD, evM, lens, dg);
+    if (__ballot(h.redo)) {
+      // a primitive right under the root's unions gave a span shorter than 1e-10: only the
+      // full sweep knows whether it survives (primitives.rs:295-298)
+      const Hit g = intersect_general(leaves, nodes, bounds, A.n_nodes, A.n_leaves, h.redo, S.o, S.d, evD, evM, lens);
+      if (h.redo) h = g;
+    }
     // ---- then the per-ray bookkeeping, out of line
-    if (S.kind != kIdle) S = after_traversal(S, h, P, A, ctx);
+    DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;)
+    if (st_kind(S.st) != kIdle) {
+      S = after_traversal(S, h, P, shade_args, ctx);
+      n_shadow += (S.st >> 24) & 1u;
+      n_reflect += (S.st >> 25) & 1u;
+      n_hits += (S.st >> 26) & 1u;
+      S.st &= 0x00FFFFFFu;
+    }
+    DIAG(t0 = __builtin_readcyclecounter(); dg.t_after += t0 - t2;)
   }
 
   // ---- ray counters: one atomic per wave and kind
-  uint32_t n_shadow = S.n_shadow, n_reflect = S.n_reflect, n_hits = S.n_hits;
   for (int off = 32; off > 0; off >>= 1) {
     n_primary += (uint32_t)__shfl_down((int)n_primary, off);
     n_shadow += (uint32_t)__shfl_down((int)n_shadow, off);
@@ -543,6 +593,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     atomicAdd(&A.ray_counts[1], (unsigned long long)n_shadow);
     atomicAdd(&A.ray_counts[2], (unsigned long long)n_reflect);
     atomicAdd(&A.ray_counts[3], (unsigned long long)n_hits);
+    DIAG(atomicAdd(&A.diag[0], dg.t_refill); atomicAdd(&A.diag[1], dg.t_trav); atomicAdd(&A.diag[2], dg.t_after);
+         atomicAdd(&A.diag[3], dg.n_trav); atomicAdd(&A.diag[4], dg.n_bound); atomicAdd(&A.diag[5], dg.n_skip);
+         atomicAdd(&A.diag[6], dg.n_leaf); atomicAdd(&A.diag[7], dg.n_merge); atomicAdd(&A.diag[8], dg.n_take);
+         atomicAdd(&A.diag[9], dg.lanes);)
   }
 }
 
@@ -586,7 +640,13 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   std::memcpy(&out->hdr, blob, sizeof(out->hdr));
   HIP_TRY(hipMalloc(&out->d_blob, bytes));
   HIP_TRY(hipMemcpy(out->d_blob, blob, bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&out->d_counters, 64));
+  {
+    std::vector<uint8_t> prog = derive_stream_program(blob);
+    out->n_prog = (uint32_t)prog.size();
+    HIP_TRY(hipMalloc(&out->d_prog, prog.size()));
+    HIP_TRY(hipMemcpy(out->d_prog, prog.data(), prog.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMalloc(&out->d_counters, 512));
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
@@ -599,6 +659,7 @@ void dev_scene_destroy(DeviceScene* s) {
   if (!s || s->device < 0) return;
   if (hipSetDevice(s->device) != hipSuccess) return;
   (void)hipFree(s->d_blob);
+  (void)hipFree(s->d_prog);
   (void)hipFree(s->d_ev_dist);
   (void)hipFree(s->d_ev_meta);
   (void)hipFree(s->d_ctx);
@@ -626,6 +687,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   std::memset(&A, 0, sizeof(A));
   A.n_leaves = H.n_leaves;
   A.n_nodes = H.n_nodes;
+  A.n_prog = s->n_prog;
   A.n_lights = H.n_lights;
   A.max_stack = H.max_stack;
   for (int i = 0; i < 3; i++) A.amb[i] = p.amb[i];
@@ -708,11 +770,21 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.ctx_fields = (uint32_t)s->ctx_fields_alloc;
   A.next_slot = (unsigned int*)s->d_counters;
   A.ray_counts = (unsigned long long*)((uint8_t*)s->d_counters + 8);
+  A.diag = (unsigned long long*)((uint8_t*)s->d_counters + 64);
 
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64, stream));
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 256, stream));
+  ShadeArgs SA;
+  std::memset(&SA, 0, sizeof(SA));
+  for (int i = 0; i < 3; i++) SA.amb[i] = p.amb[i];
+  SA.depth = A.depth;
+  SA.n_lights = A.n_lights;
+  SA.ctx_fields = A.ctx_fields;
+  SA.rgb8 = A.rgb8;
+  SA.rgbf = A.rgbf;
+  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                     d_code, d_consts, d_bounds, A);
+                     d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   unsigned long long counts[4] = {0, 0, 0, 0};
@@ -720,6 +792,18 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
+#ifdef GMLRT_DIAG
+  {
+    unsigned long long dgv[10];
+    HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + 64, sizeof(dgv), hipMemcpyDeviceToHost));
+    const double nt = (double)dgv[3] > 0 ? (double)dgv[3] : 1.0;
+    std::fprintf(stderr,
+                 "[gmlrt diag] wave-traversals %llu (avg lanes %.1f); per traversal: bounds %.1f (skipped %.1f) leaves %.1f "
+                 "merges %.2f takes %.1f; cycles/traversal: refill %.0f traverse %.0f after %.0f\n",
+                 dgv[3], (double)dgv[9] / nt, (double)dgv[4] / nt, (double)dgv[5] / nt, (double)dgv[6] / nt, (double)dgv[7] / nt,
+                 (double)dgv[8] / nt, (double)dgv[0] / nt, (double)dgv[1] / nt, (double)dgv[2] / nt);
+  }
+#endif
   if (stats) {
     stats->rays_primary = counts[0];
     stats->rays_shadow = counts[1];

@@ -1,0 +1,141 @@
+// Fragment of gmlrt_kernels.hip (included inside its anonymous namespace, after
+// merge_lists and the event-meta constants): the traversal the kernel runs.
+//
+// It interprets the derived program of gmlrt_program.cpp, a byte stream of records
+// with inline operands, so each step is one round of scalar loads from a
+// wave-uniform address.  The tree of unions under the root keeps only the nearest
+// first Entry of its children (`best`); every other operator is evaluated with
+// lists exactly as intersect_general does.
+
+__device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
+                                      uint32_t n_leaves, bool active, V3 o, V3 d, double* __restrict__ evD,
+                                      uint32_t* __restrict__ evM, uint16_t* __restrict__ lens, Diag& dg) {
+  Hit h = {false, 0.0, 0u, false};
+  if (n_leaves == 1) {
+    // The root is a bare primitive: its raw list is what trace sees, a lone Exit included.
+    double scale; V3 rd, rp;
+    to_object(leaves->inv_m, o, d, scale, rd, rp);
+    PrimHit ph = isect_prim(leaves->type, rp, rd);
+    if (active && ph.bits) {
+      h.any = true;
+      if (ph.bits & 1) { h.dist = scale * ph.tA; h.meta = ((uint32_t)ph.fA << kFaceShift); }
+      else { h.dist = scale * ph.tB; h.meta = ((uint32_t)ph.fB << kFaceShift) | kOrigExit | kCurExit; }
+    }
+    return h;
+  }
+  bool found = false, redo = false;
+  double best = 0.0;
+  uint32_t best_m = 0u;
+  uint32_t sp = 0;     // events on this lane's stack
+  uint32_t level = 0;  // operand stack depth (wave-uniform)
+  const int tid = threadIdx.x;
+  uint32_t pc = 0;     // byte offset of the current record (wave-uniform)
+  for (;;) {
+    const ProgSmall* __restrict__ rec = (const ProgSmall*)(prog + pc);
+    const uint32_t kf = rec->kind;
+    const uint32_t kind = kf & 0xFu;
+    if (kind == kRecBound) {
+      // Bounding sphere in front of a subtree: if no lane's ray comes near it, every
+      // list below is empty.  Under the union frontier that means "nothing to take";
+      // inside a frontier child the subtree's (empty) list is pushed.
+      const ProgBound* __restrict__ B = (const ProgBound*)(prog + pc);
+      const V3 oc = {B->center[0] - o.x, B->center[1] - o.y, B->center[2] - o.z};
+      const double tca = vdot(oc, d);
+      const V3 perp = vsub(oc, vmul(d, tca));
+      const double r2 = B->radius2;
+      // any NaN compares false and keeps the subtree
+      const bool miss = !active || vdot(perp, perp) > r2 || (tca < 0.0 && vdot(oc, oc) > r2);
+      DIAG(dg.n_bound++;)
+      if (!__ballot(!miss)) {
+        DIAG(dg.n_skip++;)
+        if (!(kf & kRecFlag)) {
+          lens[level * kBlock + tid] = 0;
+          level++;
+        }
+        pc = B->skip_to;
+      } else {
+        pc += (uint32_t)sizeof(ProgBound);
+      }
+    } else if (kind == kRecLeaf) {
+      const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
+      double scale; V3 rd, rp;
+      to_object(L->inv_m, o, d, scale, rd, rp);
+      PrimHit ph = isect_prim((kf >> 16) & 7u, rp, rd);
+      const uint32_t leaf = L->leaf;
+      DIAG(dg.n_leaf++;)
+      // a list that starts with Exit never raises its operand's counter above zero
+      // (primitives.rs:254-293 start both counters at 0): same as no list at all
+      const bool entry = active && (ph.bits & 1);
+      const double d0 = scale * ph.tA, d1 = scale * ph.tB;
+      const bool sliver = (ph.bits & 2) && (d1 - d0 < 1e-10);
+      if (kf & kRecFlag) {
+        // frontier leaf: no list, just a candidate for the nearest first Entry
+        if (entry) {
+          if (sliver) redo = true;
+          else if (!found || d0 < best) { found = true; best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift); }
+        }
+      } else {
+        uint32_t n = 0;
+        if (entry) {
+          evD[(size_t)sp * kWave] = d0;
+          evM[(size_t)sp * kWave] = leaf | ((uint32_t)ph.fA << kFaceShift);
+          n = 1;
+          if (ph.bits & 2) {
+            evD[(size_t)(sp + 1) * kWave] = d1;
+            evM[(size_t)(sp + 1) * kWave] = leaf | ((uint32_t)ph.fB << kFaceShift) | kOrigExit | kCurExit;
+            n = sliver ? (2u | 0x8000u) : 2u;
+          }
+        }
+        lens[level * kBlock + tid] = (uint16_t)n;
+        sp += n & 0x7FFFu;
+        level++;
+      }
+      pc += (uint32_t)sizeof(ProgLeaf);
+    } else if (kind == kRecOp) {
+      const uint32_t rule = rec->arg & 3u;
+      const uint32_t lenB = lens[(level - 1) * kBlock + tid], lenA = lens[(level - 2) * kBlock + tid];
+      const uint32_t lb = lenB & 0x7FFFu, la = lenA & 0x7FFFu;
+      const bool slvA = lenA >> 15, slvB = lenB >> 15;
+      const uint32_t a0 = sp - la - lb;
+      uint32_t lout = 0;
+      bool general = false;
+      if (rule == GMLRT_UNION) {
+        if (lb == 0) lout = slvA ? 0 : la;
+        else if (la == 0) lout = slvB ? 0 : lb;  // B already sits at a0
+        else general = true;
+      } else if (rule == GMLRT_INTERSECT) {
+        general = la != 0 && lb != 0;
+      } else {
+        if (la != 0) {
+          if (lb == 0) lout = slvA ? 0 : la;
+          else general = true;
+        }
+      }
+      DIAG(if (__ballot(general)) dg.n_merge++;)
+      if (general) lout = merge_lists(rule, evD, evM, a0, la, lb);
+      lens[(level - 2) * kBlock + tid] = (uint16_t)lout;
+      sp = a0 + lout;
+      level--;
+      pc += (uint32_t)sizeof(ProgSmall);
+    } else if (kind == kRecTake) {
+      // a frontier child is complete: its list is the only one on the stack and, being an
+      // operator's output, starts with an Entry and holds no sliver
+      const uint32_t n = lens[tid] & 0x7FFFu;
+      DIAG(dg.n_take++;)
+      if (active && n) {
+        const double d0 = evD[0];
+        if (!found || d0 < best) { found = true; best = d0; best_m = evM[0]; }
+      }
+      sp = 0;
+      level = 0;
+      pc += (uint32_t)sizeof(ProgSmall);
+    } else {
+      break;  // kRecEnd
+    }
+  }
+  h.any = found;
+  h.dist = best;
+  h.meta = best_m;
+  h.redo = redo;
+  return h;
+}

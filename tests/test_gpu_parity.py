@@ -118,3 +118,35 @@ def test_full_size_rows_against_oracle(gmlrt, oracle):
     frac1, maxd, ndiff = image_diff(img[rows], ref)
     print("4K rows: within1=%.6f max=%d differing=%d" % (frac1, maxd, ndiff))
     assert frac1 >= 0.999 and maxd <= 8
+
+
+SURF = "{ /v /u /face 0.9 0.8 0.7 point 0.8 0.3 4.0 } /m "
+LIGHT = "1.0 -1.0 1.0 point 1.0 1.0 1.0 point light /l "
+
+
+@pytest.mark.parametrize("label,scene", [
+    # a plate 1e-11 thick right under the root union: every ray through it yields a span shorter than 1e-10, which the
+    # reference pops (primitives.rs:295-298) unless a neighbour extends it -> exercises the full-sweep re-run
+    ("sliver_plate", "m cube 2.0 2.0 1e-11 scale -1.0 -1.0 3.0 translate m sphere 0.0 0.0 5.0 translate union "
+                     "m plane 0.0 -1.5 0.0 translate union"),
+    # the same plate glued to the front face of a cube: the cube's span extends the plate's
+    ("sliver_on_cube", "m cube 2.0 2.0 1e-11 scale -1.0 -1.0 3.0 translate m cube 2.0 2.0 1.0 scale -1.0 -1.0 3.0 translate "
+                       "union m plane 0.0 -1.5 0.0 translate union"),
+    # root is not a union: the whole tree is one frontier child
+    ("root_difference", "m sphere 1.5 uscale 0.0 0.0 4.0 translate m cylinder 0.5 4.0 0.5 scale 0.0 -2.0 4.0 translate difference"),
+    ("root_intersect", "m sphere 1.5 uscale 0.0 0.0 4.0 translate m cube 2.0 2.0 2.0 scale -1.0 -1.0 2.5 translate intersect"),
+    # unions of operator children, nested on both sides, with coincident faces
+    ("nested", "m cube -0.5 -0.5 3.0 translate m sphere 0.6 uscale 0.0 0.0 3.0 translate difference "
+               "m cone 0.0 -1.0 0.0 translate 1.0 2.0 1.0 scale 1.5 0.0 4.0 translate m cylinder -1.5 -1.0 4.0 translate union union "
+               "m plane 0.0 -1.0 0.0 translate union"),
+])
+def test_union_frontier_cases(gmlrt, oracle, label, scene):
+    text = SURF + LIGHT + scene + ' /s 0.3 0.3 0.3 point [ l ] s 3 90.0 160 120 "x.ppm" render'
+    img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print(label, "differing=%d max=%d" % (ndiff, maxd), st.as_dict())
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert np.abs(f64 - ref64).max() <= 1e-9
+    assert img.any()

@@ -12,4 +12,4 @@ make -s -C $C -j8 ../libgmlrt.so >/dev/null
   -c $C/gmlrt_kernels.hip -o $C/build/kernels_$NAME.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "VGPRs:|AGPRs|Scratch|Occupancy|Spill|error" | tr '\n' ' '
 echo
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/rust-raytracer_amd/variants/libgmlrt_$NAME.so \
-  $C/build/gml_front.o $C/build/gmlrt_scene.o $C/build/gmlrt_api.o $C/build/kernels_$NAME.o -pthread
+  $C/build/gml_front.o $C/build/gmlrt_scene.o $C/build/gmlrt_program.o $C/build/gmlrt_api.o $C/build/kernels_$NAME.o -pthread
