@@ -45,6 +45,7 @@ struct DeviceScene {
   size_t blob_bytes = 0;
   void* d_prog = nullptr;       // derived program (record stream)
   uint32_t n_prog = 0;          // its size in bytes
+  uint32_t n_vm_regs = 0;       // registers the scene's surface bytecode uses
   gmlrt_blob_header hdr{};
   // workspace, grown on demand and kept for the life of the handle
   void* d_ev_dist = nullptr;

@@ -38,6 +38,7 @@ constexpr uint32_t kLeafMask = 0xFFFFFu;
 constexpr uint32_t kFaceShift = 20;
 constexpr uint32_t kOrigExit = 1u << 23;  // the primitive produced this event as an Exit
 constexpr uint32_t kCurExit = 1u << 24;   // current type after operator switches
+constexpr uint32_t kHitAny = 1u << 31;    // set in the meta word handed to after_traversal: the ray hit something
 constexpr int kCtxFixed = 27;             // f64 fields of the shading context before the bounce stack
 constexpr int kCtxPerLevel = 7;
 
@@ -71,6 +72,8 @@ struct KArgs {
   uint32_t ev_cap;       // event slots per lane
   double* ctx;
   uint32_t ctx_fields;
+  uint32_t n_vm_fast;    // surface-bytecode registers kept in LDS (the rest live in the context record)
+  uint32_t vm_lds_off;   // byte offset of that LDS region (after the operand-stack lengths)
   unsigned int* next_slot;
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
@@ -84,9 +87,15 @@ struct ShadeArgs {
   int32_t depth;
   uint32_t n_lights;
   uint32_t ctx_fields;
+  uint32_t n_vm_fast;  // surface-bytecode registers kept in LDS
+  uint32_t vm_all_fast;  // 1: that is all the registers the scene's bytecode uses
   uint32_t pad;
   uint8_t* rgb8;
   double* rgbf;
+  const gmlrt_leaf* leaves;
+  const gmlrt_light* lights;
+  const uint64_t* code;
+  const uint64_t* consts;
 };
 
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
@@ -98,6 +107,23 @@ struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_s
 #else
 #define DIAG(x)
 #endif
+
+// Pointers reach an out-of-line device function as generic ("flat") addresses in
+// vector registers.  These helpers restate what the caller knows: which memory the
+// pointer is in (so accesses become global_/ds_ instructions instead of flat_) and,
+// for wave_uniform, that every lane holds the same value (so read-only data can be
+// fetched with scalar loads).
+#define GMLRT_AS(n) __attribute__((address_space(n)))
+template <class T>
+__device__ inline T* global_space(T* p) { return (T*)(GMLRT_AS(1) T*)(uintptr_t)p; }
+template <class T>
+__device__ inline const T* const_space(const T* p) { return (const T*)(const GMLRT_AS(4) T*)(uintptr_t)p; }
+template <class T>
+__device__ inline T* wave_uniform(T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
 
 // ---------------------------------------------------------------- CSG traversal
 // First element of the root list.  redo: the shortcut traversal met a case it does
@@ -112,8 +138,10 @@ __device__ inline bool csg_rule(uint32_t rule, bool a, bool b) {
 // above the other on the lane's event stack (A at a0, B right after it).  Both
 // inputs are already sorted, so the stable sort of their concatenation is a merge
 // that takes A on ties.  Output goes above B and is then moved down onto A.
-__device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__ evD, uint32_t* __restrict__ evM,
+__device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
                                              uint32_t a0, uint32_t la, uint32_t lb) {
+  double* __restrict__ evD = global_space(evD_v);
+  uint32_t* __restrict__ evM = global_space(evM_v);
   const uint32_t b0 = a0 + la, out0 = b0 + lb;
   uint32_t i = 0, j = 0, k = 0;
   bool in1 = false, in2 = false, inside = false;
@@ -301,13 +329,6 @@ __device__ inline uint8_t quantise(double p) {
   return (uint8_t)v;
 }
 
-#define CTX(f) ctx[(size_t)(f) * kWave]
-__device__ inline V3 ctx_get3(const double* ctx, int f) { return {CTX(f), CTX(f + 1), CTX(f + 2)}; }
-__device__ inline void ctx_set3(double* ctx, int f, V3 v) { CTX(f) = v.x; CTX(f + 1) = v.y; CTX(f + 2) = v.z; }
-// context fields
-enum { F_POS = 0, F_NRM = 3, F_SC = 6, F_KD = 9, F_KS = 10, F_N = 11, F_C = 12, F_DIFF = 15, F_SPEC = 18,
-       F_RPOS = 21, F_RDIR = 24 };
-
 // What a lane carries from one traversal to the next.  Kept to 56 bytes so that it
 // travels to and from the out-of-line code in registers (a larger struct would be
 // passed through the stack, i.e. scratch memory).
@@ -320,169 +341,7 @@ struct LaneState {
 constexpr uint32_t kStShadow = 1u << 24, kStReflect = 1u << 25, kStHit = 1u << 26;
 __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 
-// Everything trace() does around its intersect calls (raytracer.rs:53-110), cut at
-// those calls: consumes the traversal result of the ray the lane holds and leaves
-// either the next ray to traverse in S or an idle lane with its pixel written.
-__device__ __noinline__ LaneState after_traversal(LaneState S, const Hit h, const ScenePtrs P, const ShadeArgs* __restrict__ SA,
-                                                  double* __restrict__ ctx) {
-  int kind = st_kind(S.st);
-  int level = (int)((S.st >> 2) & 0x7FFu);
-  uint32_t li = (S.st >> 13) & 0x7FFu;
-  uint32_t events = 0;
-  bool advance = false, finish = false;
-  V3 C = {0.0, 0.0, 0.0};  // value of trace() at level when finish is set
-
-  if (kind == kView) {
-    if (!h.any || (h.meta & kCurExit)) {
-      finish = true;  // raytracer.rs:55-57, 108-110
-    } else {
-      // ---- raytracer.rs:58-68: surface, position, normal of the hit
-      const gmlrt_leaf* L = P.leaves + (h.meta & kLeafMask);
-      const int face = (int)((h.meta >> kFaceShift) & 7u);
-      double scale; V3 rd, rp;
-      to_object(L->inv_m, S.o, S.d, scale, rd, rp);
-      const uint32_t type = L->type;
-      PrimHit ph = isect_prim(type, rp, rd);
-      const double od = (h.meta & kOrigExit) ? ph.tB : ph.tA;
-      const V3 opos = vadd(rp, vmul(rd, od));
-      double u, v;
-      prim_uv(type, face, opos, u, v);
-      double s6[6];
-      const uint32_t mycode = L->surf_code;
-      const uint64_t* kc = P.consts + L->surf_const;
-      if (mycode == GMLRT_SURF_CONST) {
-#pragma unroll
-        for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
-      } else {
-        // run each distinct program once for the lanes that share it
-        bool pending = true;
-        while (pending) {
-          const uint32_t cur = __builtin_amdgcn_readfirstlane(mycode);
-          if (mycode == cur) {
-            // the bytecode registers live in the lane's context record, after the bounce stack
-            surface_vm(P.code + cur, kc, (int64_t)face, u, v, s6,
-                       (uint64_t*)(ctx + (size_t)(SA->ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), kWave);
-            pending = false;
-          }
-        }
-      }
-      const V3 sc = {s6[0], s6[1], s6[2]};
-      const double kd = s6[3], ks = s6[4], sn = s6[5];
-      const V3 c = vmul(vcmul({SA->amb[0], SA->amb[1], SA->amb[2]}, sc), kd);  // get_ambient
-      const double* m = L->m;
-      const V3 pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3],
-                      m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
-                      m[8] * opos.x + m[9] * opos.y + m[10] * opos.z + m[11]};
-      const V3 no = prim_normal(type, face, opos);
-      const double* im = L->inv_m;  // transform_normal: transpose(inv_m) * n  (transform.rs:34-36)
-      V3 nw = {im[0] * no.x + im[4] * no.y + im[8] * no.z, im[1] * no.x + im[5] * no.y + im[9] * no.z,
-               im[2] * no.x + im[6] * no.y + im[10] * no.z};
-      V3 normal = vnormalize(nw);
-      if (((h.meta & kCurExit) != 0) != ((h.meta & kOrigExit) != 0)) normal = vneg(normal);
-      ctx_set3(ctx, F_POS, pos);
-      ctx_set3(ctx, F_NRM, normal);
-      ctx_set3(ctx, F_SC, sc);
-      CTX(F_KD) = kd; CTX(F_KS) = ks; CTX(F_N) = sn;
-      ctx_set3(ctx, F_C, c);
-      ctx_set3(ctx, F_DIFF, {0.0, 0.0, 0.0});
-      ctx_set3(ctx, F_SPEC, {0.0, 0.0, 0.0});
-      ctx_set3(ctx, F_RPOS, S.o);
-      ctx_set3(ctx, F_RDIR, S.d);
-      li = 0;
-      events |= kStHit;
-      advance = true;
-    }
-  } else if (kind == kShadow) {
-    // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
-    const gmlrt_light& l = P.lights[li];
-    const V3 pos = ctx_get3(ctx, F_POS);
-    V3 ldir; bool has_ld; double ld;
-    light_direction(l, pos, ldir, has_ld, ld);
-    bool lit = !h.any;
-    if (!lit && has_ld && ld < h.dist) lit = true;
-    if (lit) {
-      const V3 normal = ctx_get3(ctx, F_NRM);
-      const V3 sc = ctx_get3(ctx, F_SC);
-      const double kd = CTX(F_KD), ks = CTX(F_KS);
-      const double df = vdot(normal, ldir);
-      const V3 ic = vcmul(sc, light_intensity(l, pos));
-      if (kd > 0.0) ctx_set3(ctx, F_DIFF, vadd(ctx_get3(ctx, F_DIFF), vmul(ic, df)));
-      if (ks > 0.0) {
-        // get_specular, raytracer.rs:34-42
-        const V3 raypos = ctx_get3(ctx, F_RPOS);
-        const V3 halfway = vnormalize(vadd(ldir, vnormalize(vsub(raypos, pos))));
-        const double sp = vdot(normal, halfway);
-        if (sp > 0.0) ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), vmul(ic, pow(sp, CTX(F_N)))));
-        else ctx_set3(ctx, F_SPEC, vadd(ctx_get3(ctx, F_SPEC), {0.0, 0.0, 0.0}));
-      }
-    }
-    li++;
-    advance = true;
-  }
-
-  if (advance) {
-    // ---- raytracer.rs:69-74: next light that faces the surface gets a shadow ray
-    const V3 pos = ctx_get3(ctx, F_POS);
-    const V3 normal = ctx_get3(ctx, F_NRM);
-    bool spawned = false;
-    while (li < SA->n_lights) {
-      V3 ldir; bool has_ld; double ld;
-      light_direction(P.lights[li], pos, ldir, has_ld, ld);
-      if (vdot(normal, ldir) > 0.0) {
-        S.o = vadd(pos, vmul(ldir, 1e-7));
-        S.d = ldir;
-        kind = kShadow;
-        events |= kStShadow;
-        spawned = true;
-        break;
-      }
-      li++;
-    }
-    if (!spawned) {
-      // ---- raytracer.rs:96-107
-      const double kd = CTX(F_KD), ks = CTX(F_KS);
-      const V3 diff = vmul(ctx_get3(ctx, F_DIFF), kd);
-      const V3 spec = vmul(ctx_get3(ctx, F_SPEC), ks);
-      const V3 c = vadd(ctx_get3(ctx, F_C), vadd(diff, spec));
-      if (ks > 0.0 && (SA->depth - level) > 0) {
-        const V3 raydir = ctx_get3(ctx, F_RDIR);
-        const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
-        // park (c, sc, ks) until the bounce below returns
-        const int f = kCtxFixed + level * kCtxPerLevel;
-        ctx_set3(ctx, f, c);
-        ctx_set3(ctx, f + 3, ctx_get3(ctx, F_SC));
-        CTX(f + 6) = ks;
-        S.o = vadd(pos, vmul(refl, 1e-7));
-        S.d = refl;
-        kind = kView;
-        level++;
-        events |= kStReflect;
-      } else {
-        C = c;
-        finish = true;
-      }
-    }
-  }
-
-  if (finish) {
-    // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
-    for (int lv = level - 1; lv >= 0; lv--) {
-      const int f = kCtxFixed + lv * kCtxPerLevel;
-      const V3 c = ctx_get3(ctx, f);
-      const V3 sc = ctx_get3(ctx, f + 3);
-      const double ks = CTX(f + 6);
-      C = vadd(c, vmul(vcmul(C, sc), ks));
-    }
-    const size_t oidx = (size_t)S.pix * 3;
-    SA->rgb8[oidx] = quantise(C.x);
-    SA->rgb8[oidx + 1] = quantise(C.y);
-    SA->rgb8[oidx + 2] = quantise(C.z);
-    if (SA->rgbf) { SA->rgbf[oidx] = C.x; SA->rgbf[oidx + 1] = C.y; SA->rgbf[oidx + 2] = C.z; }
-    kind = kIdle;
-  }
-  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | events;
-  return S;
-}
+#include "gmlrt_shade.hpp"
 
 #ifndef GMLRT_WAVES_PER_SIMD
 #define GMLRT_WAVES_PER_SIMD 4  // measured on chess 4K depth 5: 3 -> 1796, 4 -> 1955, 5 -> 1655, 6 -> 1794 Mrays/s
@@ -491,14 +350,14 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
     const uint8_t* __restrict__ prog, const ShadeArgs* __restrict__ shade_args, const KArgs A) {
-  extern __shared__ uint16_t lens[];
+  extern __shared__ __align__(16) uint16_t lens[];
   const int tid = threadIdx.x;
+  uint64_t* vm_fast = (uint64_t*)((uint8_t*)lens + A.vm_lds_off) + tid;
   const int lane = tid & (kWave - 1);
   const size_t wave = (size_t)blockIdx.x * (kBlock / kWave) + (size_t)(tid / kWave);
   double* __restrict__ evD = A.ev_dist + wave * A.ev_cap * kWave + lane;
   uint32_t* __restrict__ evM = A.ev_meta + wave * A.ev_cap * kWave + lane;
   double* __restrict__ ctx = A.ctx + wave * A.ctx_fields * kWave + lane;
-  const ScenePtrs P = {leaves, nodes, lights, code, consts};
 
   LaneState S;
   S.o = {0, 0, 0};
@@ -572,7 +431,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- then the per-ray bookkeeping, out of line
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;)
     if (st_kind(S.st) != kIdle) {
-      S = after_traversal(S, h, P, shade_args, ctx);
+      S = after_traversal(S, h.dist, h.any ? (h.meta | kHitAny) : 0u, shade_args, ctx, vm_fast);
       n_shadow += (S.st >> 24) & 1u;
       n_reflect += (S.st >> 25) & 1u;
       n_hits += (S.st >> 26) & 1u;
@@ -645,6 +504,18 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     out->n_prog = (uint32_t)prog.size();
     HIP_TRY(hipMalloc(&out->d_prog, prog.size()));
     HIP_TRY(hipMemcpy(out->d_prog, prog.data(), prog.size(), hipMemcpyHostToDevice));
+  }
+  {
+    // highest register any surface program writes (OUT's dst field is a slot selector, not a register)
+    const gmlrt_blob_header& H = out->hdr;
+    const uint64_t* code = (const uint64_t*)((const uint8_t*)blob + H.off_code);
+    uint32_t top = 2;  // face, u, v
+    for (uint64_t i = 0; i < H.n_code_words; i++) {
+      const uint32_t op = (uint32_t)(code[i] & 0xFF), dst = (uint32_t)((code[i] >> 8) & 0xFF);
+      if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT && dst > top) top = dst;
+    }
+    out->n_vm_regs = H.n_code_words ? (top & (GMLRT_SURF_MAX_REGS - 1)) + 1 : 0;
+    if (top >= GMLRT_SURF_MAX_REGS) out->n_vm_regs = GMLRT_SURF_MAX_REGS;
   }
   HIP_TRY(hipMalloc(&out->d_counters, 512));
   hipEvent_t a, b;
@@ -724,11 +595,23 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // ---- launch geometry: a persistent grid sized to what the device keeps resident
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-  const size_t lds_bytes = (size_t)H.max_stack * kBlock * sizeof(uint16_t);
-  if (lds_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
+  const size_t lens_bytes = (((size_t)H.max_stack * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
+  if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
   int blocks_per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, kBlock, lds_bytes));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, kBlock, lens_bytes));
   if (blocks_per_cu < 1) blocks_per_cu = 1;
+  // The surface bytecode's registers go to whatever LDS is left at that occupancy.
+  size_t n_vm_fast = s->n_vm_regs;
+  {
+    const size_t per_block = (size_t)prop.sharedMemPerBlock < (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu
+                                 ? (size_t)prop.sharedMemPerBlock
+                                 : (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu;
+    const size_t room = per_block > lens_bytes + 1024 ? (per_block - lens_bytes - 1024) / ((size_t)kBlock * 8) : 0;
+    if (n_vm_fast > room) n_vm_fast = room;
+  }
+  const size_t lds_bytes = lens_bytes + n_vm_fast * kBlock * sizeof(uint64_t);
+  A.n_vm_fast = (uint32_t)n_vm_fast;
+  A.vm_lds_off = (uint32_t)lens_bytes;
   uint64_t grid = (uint64_t)prop.multiProcessorCount * (uint64_t)blocks_per_cu;
   const uint64_t need = (n_slots + kBlock - 1) / kBlock;
   if (grid > need) grid = need;
@@ -779,8 +662,14 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.depth = A.depth;
   SA.n_lights = A.n_lights;
   SA.ctx_fields = A.ctx_fields;
+  SA.n_vm_fast = A.n_vm_fast;
+  SA.vm_all_fast = A.n_vm_fast >= s->n_vm_regs ? 1u : 0u;
   SA.rgb8 = A.rgb8;
   SA.rgbf = A.rgbf;
+  SA.leaves = d_leaves;
+  SA.lights = d_lights;
+  SA.code = d_code;
+  SA.consts = d_consts;
   HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,

@@ -501,7 +501,8 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
     return;
   }
   uint64_t regs[GMLRT_SURF_MAX_REGS];
-  surface_vm(p.code.data(), p.consts.data(), face, u, v, out, regs, 1);
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1};
+  surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R);
 }
 
 // ============================================================== flattening

@@ -45,15 +45,43 @@ GMLRT_HD double vm_cos(double x) { double r = cos(vm_to_radians(x)); return fabs
 GMLRT_HD double vm_frac(double x) { return x - trunc(x); }
 GMLRT_HD double vm_clampf(double x) { return fmin(fmax(x, 0.0), 1.0); }
 
+// Register storage of the interpreter: registers [0, n_fast) live at fast[i * fast_stride]
+// (the device hands in a lane-strided slice of LDS, the host a plain array), the
+// rest at slow[i * slow_stride] (device: the lane's context record in memory).
+// The pointer types are template parameters so that the device can pass pointers
+// that carry their address space (LDS, global, constant) in the type.
+template <class FastP, class SlowP>
+struct VmRegs {
+  FastP fast;
+  uint32_t fast_stride, n_fast;
+  SlowP slow;
+  uint32_t slow_stride;
+};
+// kAllFast: the caller guarantees that every register the program names is below n_fast.
+template <bool kAllFast, class RegsT>
+GMLRT_HD uint64_t vm_get(const RegsT& R, uint32_t i) {
+  if (kAllFast) return R.fast[(size_t)i * R.fast_stride];
+  if (i < R.n_fast) return R.fast[(size_t)i * R.fast_stride];
+  return R.slow[(size_t)i * R.slow_stride];
+}
+template <bool kAllFast, class RegsT>
+GMLRT_HD void vm_set(const RegsT& R, uint32_t i, uint64_t v) {
+  if (kAllFast || i < R.n_fast) R.fast[(size_t)i * R.fast_stride] = v;
+  else R.slow[(size_t)i * R.slow_stride] = v;
+}
+template <bool kAllFast, class ConstP, class RegsT>
+GMLRT_HD uint64_t vm_operand(ConstP consts, const RegsT& R, uint32_t x) {
+  if (x & 0x8000u) return consts[x & 0x7FFFu];
+  return vm_get<kAllFast>(R, x & (GMLRT_SURF_MAX_REGS - 1));
+}
+
 // Runs `code` until GMLRT_SOP_END.  consts points at this surface's first constant.
-// `r` is storage for GMLRT_SURF_MAX_REGS 8-byte registers, register i at r[i * rstride]
-// (the device hands in a lane-strided slice of its context record, the host a plain array).
-GMLRT_HD void surface_vm(const uint64_t* code, const uint64_t* consts, int64_t face, double u, double v,
-                         double out[6], uint64_t* r, size_t rstride) {
-  r[0] = (uint64_t)face;
-  r[1 * rstride] = vm_from_f64(u);
-  r[2 * rstride] = vm_from_f64(v);
-#define OPND(x) (((x) & 0x8000u) ? consts[(x) & 0x7FFFu] : r[(size_t)((x) & (GMLRT_SURF_MAX_REGS - 1)) * rstride])
+template <bool kAllFast, class CodeP, class ConstP, class RegsT>
+GMLRT_HD void surface_vm(CodeP code, ConstP consts, int64_t face, double u, double v, double out[6], const RegsT R) {
+  vm_set<kAllFast>(R, 0, (uint64_t)face);
+  vm_set<kAllFast>(R, 1, vm_from_f64(u));
+  vm_set<kAllFast>(R, 2, vm_from_f64(v));
+#define OPND(x) vm_operand<kAllFast>(consts, R, (x))
   for (uint32_t pc = 0;; pc++) {
     const uint64_t w = code[pc];
     const uint32_t op = (uint32_t)(w & 0xFF);
@@ -98,7 +126,7 @@ GMLRT_HD void surface_vm(const uint64_t* code, const uint64_t* consts, int64_t f
       }
       default: break;
     }
-    r[(size_t)(dst & (GMLRT_SURF_MAX_REGS - 1)) * rstride] = res;
+    vm_set<kAllFast>(R, dst & (GMLRT_SURF_MAX_REGS - 1), res);
   }
 #undef OPND
 }
