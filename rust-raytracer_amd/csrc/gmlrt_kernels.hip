@@ -96,6 +96,7 @@ struct ShadeArgs {
   const gmlrt_light* lights;
   const uint64_t* code;
   const uint64_t* consts;
+  unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
 };
 
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
@@ -103,9 +104,9 @@ struct ShadeArgs {
 // shares, not timings.
 struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes; };
 #ifdef GMLRT_DIAG
-#define DIAG(x) x
+#define DIAG(...) __VA_ARGS__
 #else
-#define DIAG(x)
+#define DIAG(...)
 #endif
 
 // Pointers reach an out-of-line device function as generic ("flat") addresses in
@@ -341,8 +342,17 @@ struct LaneState {
 constexpr uint32_t kStShadow = 1u << 24, kStReflect = 1u << 25, kStHit = 1u << 26;
 __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 
+#ifndef GMLRT_AFTER_INLINE
+#define GMLRT_AFTER_INLINE __noinline__
+#endif
 #include "gmlrt_shade.hpp"
 
+// Idle lanes are given new pixels only once at least this many of the wave's lanes are
+// idle: rays that start together stay in step (camera rays of one tile, then their
+// shadow rays, then their bounces), which is what lets a whole wave skip a bounded subtree.
+#ifndef GMLRT_REFILL_MIN
+#define GMLRT_REFILL_MIN 64
+#endif
 #ifndef GMLRT_WAVES_PER_SIMD
 #define GMLRT_WAVES_PER_SIMD 4  // measured on chess 4K depth 5: 3 -> 1796, 4 -> 1955, 5 -> 1655, 6 -> 1794 Mrays/s
 #endif
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   for (;;) {
     // ---- hand new pixels to idle lanes
     unsigned long long idle = __ballot(st_kind(S.st) == kIdle);
-    while (idle && (tile_left || more)) {
+    while ((uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more)) {
       if (tile_left == 0) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(A.next_slot, 64u);
@@ -670,6 +680,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.lights = d_lights;
   SA.code = d_code;
   SA.consts = d_consts;
+#ifdef GMLRT_DIAG
+  unsigned long long* d_diag_waves = nullptr;
+  HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * 8 * sizeof(unsigned long long), stream));
+  SA.diag_waves = d_diag_waves;
+#endif
   HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
@@ -683,14 +699,27 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
 #ifdef GMLRT_DIAG
   {
-    unsigned long long dgv[10];
-    HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + 64, sizeof(dgv), hipMemcpyDeviceToHost));
+    unsigned long long dgv[16];
+    HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + 64, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    {
+      std::vector<unsigned long long> per_wave(lanes / kWave * 8);
+      HIP_TRY(hipMemcpy(per_wave.data(), d_diag_waves, per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      (void)hipFree(d_diag_waves);
+      for (int q = 0; q < 6; q++) dgv[10 + q] = 0;
+      for (size_t wv = 0; wv < lanes / kWave; wv++)
+        for (int q = 0; q < 6; q++) dgv[10 + q] += per_wave[wv * 8 + q];
+    }
     const double nt = (double)dgv[3] > 0 ? (double)dgv[3] : 1.0;
     std::fprintf(stderr,
                  "[gmlrt diag] wave-traversals %llu (avg lanes %.1f); per traversal: bounds %.1f (skipped %.1f) leaves %.1f "
                  "merges %.2f takes %.1f; cycles/traversal: refill %.0f traverse %.0f after %.0f\n",
                  dgv[3], (double)dgv[9] / nt, (double)dgv[4] / nt, (double)dgv[5] / nt, (double)dgv[6] / nt, (double)dgv[7] / nt,
                  (double)dgv[8] / nt, (double)dgv[0] / nt, (double)dgv[1] / nt, (double)dgv[2] / nt);
+    std::fprintf(stderr,
+                 "[gmlrt diag] after, cycles/traversal: hit geometry %.0f surface vm %.0f shade+store %.0f shadow result %.0f "
+                 "next ray %.0f finish %.0f\n",
+                 (double)dgv[10] / nt, (double)dgv[11] / nt, (double)dgv[12] / nt, (double)dgv[13] / nt, (double)dgv[14] / nt,
+                 (double)dgv[15] / nt);
   }
 #endif
   if (stats) {

@@ -589,28 +589,49 @@ struct Flattener : gml::TreeVisitor {
 
   static Bound leaf_bound(gml::PrimType prim, const gml::Transform& t) {
     Bound b;
-    double lc[3] = {0, 0, 0}, lr = 1.0;
+    // the primitive's box in object space (primitives.rs: sphere |p| <= 1; cube [0,1]^3;
+    // cylinder and cone radius 1, 0 <= y <= 1)
+    double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
     switch (prim) {
-      case gml::PrimType::Sphere: break;                                             // |p| <= 1
-      case gml::PrimType::Cube: lc[0] = lc[1] = lc[2] = 0.5; lr = 0.8660254037844387; break;  // [0,1]^3
-      case gml::PrimType::Cylinder: lc[1] = 0.5; lr = 1.118033988749895; break;      // r 1, 0 <= y <= 1
-      case gml::PrimType::Cone: lc[1] = 1.0; lr = 1.0; break;                        // apex 0, rim radius 1 at y=1
-      default: return b;                                                              // half-space: unbounded
+      case gml::PrimType::Sphere: break;
+      case gml::PrimType::Cube: lo[0] = lo[1] = lo[2] = 0.0; break;
+      case gml::PrimType::Cylinder:
+      case gml::PrimType::Cone: lo[1] = 0.0; break;
+      default: return b;  // half-space: unbounded
     }
     const double (*M)[4] = t.m.m;
-    // largest stretch of the linear part: lambda_max(M^T M) <= its largest absolute row sum
-    double s2 = 0.0;
-    for (int i = 0; i < 3; i++) {
-      double row = 0.0;
-      for (int j = 0; j < 3; j++) {
-        double e = 0.0;
-        for (int k = 0; k < 3; k++) e += M[k][i] * M[k][j];
-        row += std::fabs(e);
-      }
-      s2 = std::max(s2, row);
-    }
+    const double lc[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
     for (int i = 0; i < 3; i++) b.c[i] = M[i][0] * lc[0] + M[i][1] * lc[1] + M[i][2] * lc[2] + M[i][3];
-    b.r = lr * std::sqrt(s2) * (1.0 + 1e-6) + 1e-9;
+    // An affine map takes the box to a parallelepiped; the farthest of its corners from the
+    // image of the centre bounds everything inside it.
+    double r2 = 0.0;
+    for (int corner = 0; corner < 8; corner++) {
+      double e[3];
+      for (int k = 0; k < 3; k++) e[k] = ((corner >> k) & 1 ? hi[k] : lo[k]) - lc[k];
+      double q = 0.0;
+      for (int i = 0; i < 3; i++) {
+        const double w = M[i][0] * e[0] + M[i][1] * e[1] + M[i][2] * e[2];
+        q += w * w;
+      }
+      r2 = std::max(r2, q);
+    }
+    double r = std::sqrt(r2);
+    if (prim == gml::PrimType::Sphere) {
+      // the unit ball itself: its image reaches no farther than the largest stretch of the linear
+      // part, lambda_max(M^T M) <= the largest absolute row sum of M^T M
+      double s2 = 0.0;
+      for (int i = 0; i < 3; i++) {
+        double row = 0.0;
+        for (int j = 0; j < 3; j++) {
+          double e = 0.0;
+          for (int k = 0; k < 3; k++) e += M[k][i] * M[k][j];
+          row += std::fabs(e);
+        }
+        s2 = std::max(s2, row);
+      }
+      r = std::min(r, std::sqrt(s2));
+    }
+    b.r = r * (1.0 + 1e-6) + 1e-9;
     b.finite = std::isfinite(b.r) && std::isfinite(b.c[0]) && std::isfinite(b.c[1]) && std::isfinite(b.c[2]);
     return b;
   }
@@ -801,8 +822,14 @@ std::string validate_blob(const void* blob, size_t bytes) {
   if (st.size() != 1 || next_leaf != h.n_leaves) return "postfix program does not reduce to one root";
   if (h.max_stack < max_stack) return "max_stack too small";
   if (h.max_events < max_events) return "max_events too small";
-  for (uint32_t i = 0; i < h.n_lights; i++)
+  for (uint32_t i = 0; i < h.n_lights; i++) {
     if (lights[i].kind > GMLRT_LIGHT_SPOT) return "bad light kind";
+    // every ray the device traces has a unit direction (its bound tests rely on it); a directional
+    // light's shadow rays take theirs from here (lights.rs:36 normalises it at construction)
+    const double* dv = lights[i].dir;
+    const double len2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+    if (lights[i].kind == GMLRT_LIGHT_DIRECTIONAL && std::fabs(len2 - 1.0) > 1e-9) return "directional light direction is not normalised";
+  }
   for (uint32_t i = 0; i < h.n_leaves; i++) {
     const gmlrt_leaf& L = leaves[i];
     if (L.type > GMLRT_PLANE) return "bad primitive type";

@@ -18,7 +18,7 @@ enum { F_POS = 0, F_NRM = 3, F_SC = 6, F_KD = 9, F_KS = 10, F_N = 11, F_C = 12, 
 // The traversal result travels as two scalars (distance; meta with kHitAny set when
 // there is a hit): together with the lane state an aggregate would exceed what the
 // calling convention passes in registers and go through the stack.
-__device__ __noinline__ LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta,
+__device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta,
                                                   const ShadeArgs* __restrict__ SA_v, double* __restrict__ ctx_v,
                                                   uint64_t* __restrict__ vm_fast_v) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
@@ -40,6 +40,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
   bool fresh = false;       // the point was shaded in this call: its ambient term and view ray are in registers
   V3 c_amb = {0, 0, 0};
 
+  DIAG(unsigned long long tq0 = __builtin_readcyclecounter(), tq1, tq2, tq3, tq4, tq5, tq6;)
   // ---- raytracer.rs:58-62: geometry of a view ray's hit in the primitive's object space
   bool shade = false;
   const gmlrt_leaf* L = P.leaves;
@@ -71,6 +72,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
   // bytecode is fetched with scalar loads); a lane keeps the result of its own pair.
   // Lanes without a hit run along on zeros; the bytecode has no trapping operation.
   double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  DIAG(tq1 = __builtin_readcyclecounter();)
   {
     typedef GMLRT_AS(3) uint64_t* LdsP;
     typedef GMLRT_AS(1) uint64_t* GlobalP;
@@ -98,6 +100,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
     }
   }
 
+  DIAG(tq2 = __builtin_readcyclecounter();)
   if (shade) {
     {
       if (mycode == GMLRT_SURF_CONST) {
@@ -131,7 +134,9 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
       events |= kStHit;
       advance = true;
     }
-  } else if (kind == kShadow) {
+  }
+  DIAG(tq3 = __builtin_readcyclecounter();)
+  if (kind == kShadow) {
     // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
     const gmlrt_light& l = P.lights[li];
     pos = ctx_get3(ctx, F_POS);
@@ -163,6 +168,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
     advance = true;
   }
 
+  DIAG(tq4 = __builtin_readcyclecounter();)
   if (advance) {
     // ---- raytracer.rs:69-74: next light that faces the surface gets a shadow ray
     bool spawned = false;
@@ -206,6 +212,7 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
     }
   }
 
+  DIAG(tq5 = __builtin_readcyclecounter();)
   if (finish) {
     // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
     for (int lv = level - 1; lv >= 0; lv--) {
@@ -224,6 +231,15 @@ __device__ __noinline__ LaneState after_traversal(LaneState S, const double h_di
     if (rgbf) { rgbf[oidx] = C.x; rgbf[oidx + 1] = C.y; rgbf[oidx + 2] = C.z; }
     kind = kIdle;
   }
+  DIAG(tq6 = __builtin_readcyclecounter();
+       const uint32_t lid = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+       if (lid == (uint32_t)__builtin_amdgcn_readfirstlane((int)lid)) {
+         // the wave's own row of the per-wave table: plain adds, no contention
+         unsigned long long* dq = global_space(wave_uniform(SA->diag_waves)) +
+                                  ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * 8;
+         dq[0] += tq1 - tq0; dq[1] += tq2 - tq1; dq[2] += tq3 - tq2; dq[3] += tq4 - tq3; dq[4] += tq5 - tq4;
+         dq[5] += tq6 - tq5;
+       })
   S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | events;
   return S;
 }

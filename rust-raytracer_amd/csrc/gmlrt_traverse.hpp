@@ -39,12 +39,15 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       // list below is empty.  Under the union frontier that means "nothing to take";
       // inside a frontier child the subtree's (empty) list is pushed.
       const ProgBound* __restrict__ B = (const ProgBound*)(prog + pc);
-      const V3 oc = {B->center[0] - o.x, B->center[1] - o.y, B->center[2] - o.z};
-      const double tca = vdot(oc, d);
-      const V3 perp = vsub(oc, vmul(d, tca));
+      // The test only has to be conservative, not reproducible, so it uses fused
+      // multiply-adds and |perp|^2 = |oc|^2 - tca^2 (d has unit length); the slack added to
+      // r^2 covers the cancellation in that difference.  Any NaN compares false and keeps
+      // the subtree.
+      const double ocx = B->center[0] - o.x, ocy = B->center[1] - o.y, ocz = B->center[2] - o.z;
+      const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
+      const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
       const double r2 = B->radius2;
-      // any NaN compares false and keeps the subtree
-      const bool miss = !active || vdot(perp, perp) > r2 || (tca < 0.0 && vdot(oc, oc) > r2);
+      const bool miss = !active || __builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2) || (tca < 0.0 && oc2 > r2);
       DIAG(dg.n_bound++;)
       if (!__ballot(!miss)) {
         DIAG(dg.n_skip++;)
