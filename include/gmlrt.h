@@ -46,7 +46,7 @@ const char* gmlrt_last_error(void);
  * header, then the sections at the byte offsets the header gives.  Little endian.
  */
 #define GMLRT_BLOB_MAGIC 0x54524C47u /* "GLRT" */
-#define GMLRT_BLOB_VERSION 2u
+#define GMLRT_BLOB_VERSION 3u
 
 enum gmlrt_prim_type { /* primitives.rs:328, 441, 576, 754, 924 */
   GMLRT_SPHERE = 0, GMLRT_CUBE = 1, GMLRT_CYLINDER = 2, GMLRT_CONE = 3, GMLRT_PLANE = 4
@@ -77,10 +77,10 @@ typedef struct gmlrt_leaf {
  *   bits 31..30 = 2: bound (optional hint, placed BEFORE the first word of a subtree):
  *                    bits 29..15 = index into the bounds section, bits 14..0 = number of
  *                    program words of that subtree (nested bound words included).
- *                    A ray that misses the bound's sphere gets an empty list for the
- *                    subtree without visiting it.  The reference has no counterpart
+ *                    A ray that misses the bound's sphere or its box gets an empty list
+ *                    for the subtree without visiting it.  The reference has no counterpart
  *                    (it tests every primitive for every ray, primitives.rs:253-315);
- *                    a bound never changes a result as long as the sphere encloses
+ *                    a bound never changes a result as long as sphere and box each enclose
  *                    every point of the subtree's solid.  Bound words are not counted
  *                    in the tree shape: n_nodes = 2*n_leaves - 1 + n_bounds. */
 #define GMLRT_NODE_LEAF(i) ((uint32_t)(i))
@@ -88,10 +88,15 @@ typedef struct gmlrt_leaf {
 #define GMLRT_NODE_BOUND(idx, nwords) (0x80000000u | ((uint32_t)(idx) << 15) | (uint32_t)(nwords))
 #define GMLRT_BOUND_MAX 32767u /* largest index / word count a bound word can carry */
 
-/* World-space sphere enclosing the solid of one subtree. */
+/* World-space sphere and axis-aligned box, each enclosing the solid of one subtree
+ * (with enough slack to cover the rounding of the intersection arithmetic).  The
+ * sphere must be finite; a box side may be +-infinity ("no information"), and
+ * lo > hi on an axis says the solid is empty.  A consumer may test either or both. */
 typedef struct gmlrt_bound {
   double center[3];
   double radius;
+  double lo[3];
+  double hi[3];
 } gmlrt_bound;
 
 typedef struct gmlrt_light {

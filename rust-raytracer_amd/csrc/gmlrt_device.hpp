@@ -14,13 +14,20 @@ namespace gmlrt {
 // Records of the derived traversal program (gmlrt_program.cpp): a byte stream of
 // 16-byte-aligned records, operands inline.  `kind` = record kind in bits 3..0,
 // kRecFlag in bit 8, a leaf's primitive type in bits 18..16.
-constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4;
+constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5;
 constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
 struct ProgBound {   // 48 bytes
   uint32_t kind;
   uint32_t skip_to;  // byte offset of the first record after the bounded subtree
   double center[3];
   double radius2;
+  uint64_t pad;
+};
+struct ProgBox {     // 64 bytes: the same as ProgBound with the subtree's box instead of its sphere
+  uint32_t kind;
+  uint32_t skip_to;
+  double lo[3];
+  double hi[3];
   uint64_t pad;
 };
 struct ProgLeaf {    // 112 bytes
@@ -34,7 +41,7 @@ struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags),
   uint32_t arg;
   uint64_t pad;
 };
-static_assert(sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
+static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
 std::vector<uint8_t> derive_stream_program(const void* blob);
 
 // Device-resident copy of one scene blob plus the per-device scratch the render

@@ -16,7 +16,10 @@
 //    their operands inline (a bound's sphere, a leaf's inverse matrix), so that one
 //    wave-uniform address gives everything a step needs in a single round of scalar
 //    loads instead of word -> index -> record.
+#include <cmath>
+#include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -26,6 +29,15 @@
 namespace gmlrt {
 
 namespace {
+// A box is chosen over the sphere when its area is below this fraction of the sphere's
+// (its test costs somewhat more).  The environment override exists for tuning runs.
+double box_bias() {
+  static const double v = [] {
+    const char* e = std::getenv("GMLRT_BOX_BIAS");
+    return e && *e ? std::atof(e) : 0.8;
+  }();
+  return v;
+}
 struct PNode {
   int a = -1, b = -1;    // children (operators)
   uint32_t word = 0;     // the leaf / operator word
@@ -85,6 +97,25 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
 
   Stream S;
   auto put_bound = [&](int idx, bool frontier) -> size_t {
+    // whichever of the two volumes a random ray is less likely to meet (smaller surface area)
+    const gmlrt_bound& g = bounds[idx];
+    bool box_ok = true;
+    for (int i = 0; i < 3; i++) box_ok = box_ok && std::isfinite(g.lo[i]) && std::isfinite(g.hi[i]);
+    if (box_ok) {
+      const double e[3] = {g.hi[0] - g.lo[0], g.hi[1] - g.lo[1], g.hi[2] - g.lo[2]};
+      const bool empty = e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0;
+      const double box_area = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+      const double sphere_area = 4.0 * 3.14159265358979323846 * g.radius * g.radius;
+      if (empty || box_area < box_bias() * sphere_area) {
+        ProgBox r;
+        std::memset(&r, 0, sizeof(r));
+        r.kind = kRecBox | (frontier ? kRecFlag : 0u);
+        // the slab test is symmetric in lo and hi, so an empty solid (lo > hi) is stated as a
+        // point no ray of interest can reach
+        for (int i = 0; i < 3; i++) { r.lo[i] = empty ? 1e300 : g.lo[i]; r.hi[i] = empty ? 1e300 : g.hi[i]; }
+        return S.put(&r, sizeof(r));
+      }
+    }
     ProgBound r;
     std::memset(&r, 0, sizeof(r));
     r.kind = kRecBound | (frontier ? kRecFlag : 0u);

@@ -1,7 +1,10 @@
 #include "gmlrt_scene.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <tuple>
 
@@ -508,6 +511,8 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
 // ============================================================== flattening
 namespace {
 
+constexpr double kInf = std::numeric_limits<double>::infinity();
+
 struct Flattener : gml::TreeVisitor {
   std::vector<gmlrt_leaf> leaves;
   std::vector<uint32_t> nodes;
@@ -573,15 +578,65 @@ struct Flattener : gml::TreeVisitor {
     n.n_leaves = tree[(size_t)n.a].n_leaves + tree[(size_t)n.b].n_leaves;
     const Bound &ba = tree[(size_t)n.a].bnd, &bb = tree[(size_t)n.b].bnd;
     // a point of the result lies in A or B (union), in A and B (intersect), in A (difference)
-    if (rule == gml::Rule::Union) n.bnd = sphere_union(ba, bb);
-    else if (rule == gml::Rule::Intersect) n.bnd = (!bb.finite || (ba.finite && ba.r <= bb.r)) ? ba : bb;
-    else n.bnd = ba;
+    if (rule == gml::Rule::Union) {
+      n.bnd = sphere_union(ba, bb);
+      for (int i = 0; i < 3; i++) { n.bnd.lo[i] = std::min(ba.lo[i], bb.lo[i]); n.bnd.hi[i] = std::max(ba.hi[i], bb.hi[i]); }
+    } else if (rule == gml::Rule::Intersect) {
+      n.bnd = (!bb.finite || (ba.finite && ba.r <= bb.r)) ? ba : bb;
+      for (int i = 0; i < 3; i++) { n.bnd.lo[i] = std::max(ba.lo[i], bb.lo[i]); n.bnd.hi[i] = std::min(ba.hi[i], bb.hi[i]); }
+    } else {
+      n.bnd = ba;
+    }
+    tighten(n.bnd);
     tstack.push_back((int)tree.size());
     tree.push_back(n);
   }
 
-  // ---- bounding spheres (acceleration hints; see GMLRT_NODE_BOUND in include/gmlrt.h)
-  struct Bound { bool finite = false; double c[3] = {0, 0, 0}; double r = 0; };
+  // ---- bounding volumes (acceleration hints; see GMLRT_NODE_BOUND in include/gmlrt.h):
+  // a sphere (finite = false: none known) and an axis-aligned box (sides may be infinite)
+  struct Bound {
+    bool finite = false;
+    double c[3] = {0, 0, 0};
+    double r = 0;
+    double lo[3] = {-kInf, -kInf, -kInf}, hi[3] = {kInf, kInf, kInf};
+    bool box_finite() const {
+      for (int i = 0; i < 3; i++) if (!std::isfinite(lo[i]) || !std::isfinite(hi[i])) return false;
+      return true;
+    }
+    bool box_empty() const { return lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]; }
+    // Surface area of the tighter of the two volumes: for convex bodies the chance that a
+    // random ray meets one is proportional to it.
+    double area() const {
+      double a = finite ? 4.0 * 3.14159265358979323846 * r * r : kInf;
+      if (box_empty()) return 0.0;
+      if (box_finite()) {
+        const double e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        a = std::min(a, 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]));
+      }
+      return a;
+    }
+  };
+  // Each volume bounds the other: a finite box has a circumscribed sphere, a sphere a
+  // circumscribed box.
+  static void tighten(Bound& b) {
+    if (b.box_empty()) {
+      // an empty solid: any small finite volume will do
+      if (!b.finite) { b.finite = true; b.c[0] = b.c[1] = b.c[2] = 0.0; }
+      b.r = 0.0;
+      return;
+    }
+    if (b.box_finite()) {
+      double h2 = 0.0, bc[3];
+      for (int i = 0; i < 3; i++) { bc[i] = 0.5 * (b.lo[i] + b.hi[i]); const double h = 0.5 * (b.hi[i] - b.lo[i]); h2 += h * h; }
+      const double br = std::sqrt(h2) * (1.0 + 1e-9) + 1e-12;
+      if (std::isfinite(br) && (!b.finite || br < b.r)) { b.finite = true; b.r = br; for (int i = 0; i < 3; i++) b.c[i] = bc[i]; }
+    }
+    if (b.finite)
+      for (int i = 0; i < 3; i++) {
+        b.lo[i] = std::max(b.lo[i], b.c[i] - b.r - 1e-12 * std::fabs(b.c[i]));
+        b.hi[i] = std::min(b.hi[i], b.c[i] + b.r + 1e-12 * std::fabs(b.c[i]));
+      }
+  }
   struct FNode { int a = -1, b = -1, leaf = -1; gml::Rule rule = gml::Rule::Union; uint32_t n_leaves = 0; Bound bnd; };
   std::vector<FNode> tree;
   std::vector<int> tstack;
@@ -597,7 +652,7 @@ struct Flattener : gml::TreeVisitor {
       case gml::PrimType::Cube: lo[0] = lo[1] = lo[2] = 0.0; break;
       case gml::PrimType::Cylinder:
       case gml::PrimType::Cone: lo[1] = 0.0; break;
-      default: return b;  // half-space: unbounded
+      default: return plane_bound(t);  // half-space: at best bounded on one side of one axis
     }
     const double (*M)[4] = t.m.m;
     const double lc[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
@@ -633,6 +688,38 @@ struct Flattener : gml::TreeVisitor {
     }
     b.r = r * (1.0 + 1e-6) + 1e-9;
     b.finite = std::isfinite(b.r) && std::isfinite(b.c[0]) && std::isfinite(b.c[1]) && std::isfinite(b.c[2]);
+    // the box: extent of the parallelepiped along each world axis (for the ball: of the ellipsoid)
+    for (int i = 0; i < 3; i++) {
+      double ext;
+      if (prim == gml::PrimType::Sphere) {
+        ext = std::sqrt(M[i][0] * M[i][0] + M[i][1] * M[i][1] + M[i][2] * M[i][2]);
+      } else {
+        ext = 0.0;
+        for (int k = 0; k < 3; k++) ext += std::fabs(M[i][k]) * 0.5 * (hi[k] - lo[k]);
+      }
+      const double slack = ext * 1e-6 + std::fabs(b.c[i]) * 1e-9 + 1e-9;
+      b.lo[i] = b.c[i] - ext - slack;
+      b.hi[i] = b.c[i] + ext + slack;
+      if (!std::isfinite(b.lo[i]) || !std::isfinite(b.hi[i])) { b.lo[i] = -kInf; b.hi[i] = kInf; }
+    }
+    if (b.finite) tighten(b);
+    return b;
+  }
+  // The solid of a plane is y <= 0 in object space (primitives.rs:924-931), i.e.
+  // n.p + t <= 0 in world space with (n, t) = row 1 of the inverse matrix.  When n is
+  // parallel to a world axis that is a bound on one side of that axis.
+  static Bound plane_bound(const gml::Transform& t) {
+    Bound b;
+    const double* row = t.inv_m.m[1];
+    int axis = -1;
+    for (int i = 0; i < 3; i++)
+      if (row[i] != 0.0) { if (axis >= 0) return b; axis = i; }
+    if (axis < 0 || !std::isfinite(row[axis]) || !std::isfinite(row[3])) return b;
+    const double edge = -row[3] / row[axis];
+    const double slack = std::fabs(edge) * 1e-6 + 1e-9;
+    if (!std::isfinite(edge)) return b;
+    if (row[axis] > 0.0) b.hi[axis] = edge + slack;
+    else b.lo[axis] = edge - slack;
     return b;
   }
   static Bound sphere_union(const Bound& p, const Bound& q) {
@@ -651,25 +738,35 @@ struct Flattener : gml::TreeVisitor {
   }
 
   // Emits the postfix program of subtree `n`.  A bound word goes in front of it when
-  // its sphere is finite and clearly tighter than the nearest enclosing emitted one
-  // (testing nested spheres of almost the same size costs more than it saves).
-  void emit(int ni, double enclosing_r) {
+  // its volume is finite and clearly tighter than the nearest enclosing emitted one
+  // (testing nested volumes of almost the same size costs more than it saves).
+  static double ratio_from_env(const char* name, double dflt) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    const double v = std::atof(e);
+    return v > 0.0 ? v : dflt;
+  }
+  // surface-area ratios; the environment overrides exist for tuning runs
+  static double op_ratio() { static const double v = ratio_from_env("GMLRT_BOUND_OP_RATIO", 0.8); return v; }
+  static double leaf_ratio() { static const double v = ratio_from_env("GMLRT_BOUND_LEAF_RATIO", 0.8); return v; }
+  void emit(int ni, double enclosing_area) {
     const FNode& n = tree[(size_t)ni];
     const bool is_leaf = n.leaf >= 0;
     const uint64_t worst_words = 2ull * (2ull * n.n_leaves - 1ull);
+    const double area = n.bnd.area();
     bool want = n.bnd.finite && bounds.size() < GMLRT_BOUND_MAX && worst_words <= GMLRT_BOUND_MAX;
-    if (want && std::isfinite(enclosing_r)) want = n.bnd.r <= (is_leaf ? 0.5 : 0.7) * enclosing_r;
+    if (want && std::isfinite(enclosing_area)) want = area <= (is_leaf ? leaf_ratio() : op_ratio()) * enclosing_area;
     size_t at = 0;
     if (want) {
       at = nodes.size();
       nodes.push_back(0);
       gmlrt_bound g;
-      for (int i = 0; i < 3; i++) g.center[i] = n.bnd.c[i];
+      for (int i = 0; i < 3; i++) { g.center[i] = n.bnd.c[i]; g.lo[i] = n.bnd.lo[i]; g.hi[i] = n.bnd.hi[i]; }
       g.radius = n.bnd.r;
       bounds.push_back(g);
     }
     const size_t my_bound = bounds.size() - 1;
-    const double inner_r = want ? n.bnd.r : enclosing_r;
+    const double inner_r = want ? area : enclosing_area;
     if (is_leaf) {
       nodes.push_back(GMLRT_NODE_LEAF(n.leaf));
       ostack.emplace_back(true, 2);
@@ -766,6 +863,9 @@ std::string validate_blob(const void* blob, size_t bytes) {
     if (!(bnds[i].radius >= 0.0) || !std::isfinite(bnds[i].radius) || !std::isfinite(bnds[i].center[0]) ||
         !std::isfinite(bnds[i].center[1]) || !std::isfinite(bnds[i].center[2]))
       return "bound is not a finite sphere";
+  for (uint32_t i = 0; i < h.n_bounds; i++)
+    for (int k = 0; k < 3; k++)
+      if (bnds[i].lo[k] != bnds[i].lo[k] || bnds[i].hi[k] != bnds[i].hi[k]) return "bound box side is NaN";
   // open bound words: (index of the first word after the subtree, operand-stack depth when it opened)
   std::vector<std::pair<uint32_t, size_t>> open_bounds;
   uint32_t bounds_seen = 0;

@@ -30,6 +30,8 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
   uint32_t level = 0;  // operand stack depth (wave-uniform)
   const int tid = threadIdx.x;
   uint32_t pc = 0;     // byte offset of the current record (wave-uniform)
+  // for the box tests; a zero component gives +-inf, which the slab arithmetic below handles
+  const V3 inv_d = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
   for (;;) {
     const ProgSmall* __restrict__ rec = (const ProgSmall*)(prog + pc);
     const uint32_t kf = rec->kind;
@@ -58,6 +60,29 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
         pc = B->skip_to;
       } else {
         pc += (uint32_t)sizeof(ProgBound);
+      }
+    } else if (kind == kRecBox) {
+      // The same for the subtree's axis-aligned box: slab test.  fmin/fmax return the
+      // other operand when one is NaN (0 * inf: the ray runs inside a face plane), which
+      // leaves that slab out; a NaN direction keeps the subtree.
+      const ProgBox* __restrict__ B = (const ProgBox*)(prog + pc);
+      const double x1 = (B->lo[0] - o.x) * inv_d.x, x2 = (B->hi[0] - o.x) * inv_d.x;
+      const double y1 = (B->lo[1] - o.y) * inv_d.y, y2 = (B->hi[1] - o.y) * inv_d.y;
+      const double z1 = (B->lo[2] - o.z) * inv_d.z, z2 = (B->hi[2] - o.z) * inv_d.z;
+      const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
+      const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+      // the relative slack covers the rounding of the six products
+      const bool miss = !active || tfar * (1.0 + 1e-9) < tnear;
+      DIAG(dg.n_bound++;)
+      if (!__ballot(!miss)) {
+        DIAG(dg.n_skip++;)
+        if (!(kf & kRecFlag)) {
+          lens[level * kBlock + tid] = 0;
+          level++;
+        }
+        pc = B->skip_to;
+      } else {
+        pc += (uint32_t)sizeof(ProgBox);
       }
     } else if (kind == kRecLeaf) {
       const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
