@@ -150,3 +150,37 @@ def test_union_frontier_cases(gmlrt, oracle, label, scene):
     assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
     assert np.abs(f64 - ref64).max() <= 1e-9
     assert img.any()
+
+
+@pytest.mark.parametrize("label,scene,size", [
+    # axis-aligned boxes and cylinders, odd image size (the centre column and row look straight down an axis),
+    # light straight from above: shadow rays with two zero direction components, mirror bounces along axes
+    ("boxes_axis_rays",
+     "m cube 1.0 1.0 1.0 scale -0.5 -1.0 3.0 translate m cube 0.5 2.0 0.5 scale 1.0 -1.0 4.0 translate union "
+     "m cylinder 0.4 1.5 0.4 scale -1.5 -1.0 3.5 translate union m cube 0.6 0.6 0.6 scale 0.0 0.2 3.2 translate union "
+     "m sphere 0.3 uscale 0.0 1.2 3.5 translate union m plane 0.0 -1.0 0.0 translate union", (161, 121)),
+    # objects whose faces sit on the planes x = 0, y = 0 that contain the camera (slab products 0 * inf)
+    ("faces_through_camera",
+     "m cube 1.0 1.0 1.0 scale 0.0 0.0 2.0 translate m cube 1.0 1.0 1.0 scale -1.0 -1.0 3.0 translate union "
+     "m cylinder 0.5 1.0 0.5 scale 0.0 -1.0 5.0 translate union m plane 0.0 -1.0 0.0 translate union", (129, 97)),
+    # bounded pieces inside intersections and differences (boxes of operator nodes)
+    ("boxed_operators",
+     "m cube 2.0 2.0 2.0 scale -1.0 -1.0 3.0 translate m sphere 1.3 uscale 0.0 0.0 4.0 translate intersect "
+     "m cylinder 0.5 4.0 0.5 scale 0.0 -2.0 4.0 translate difference "
+     "m cone 0.0 -1.0 0.0 translate 0.7 1.5 0.7 scale 2.2 0.5 4.5 translate m plane 0.0 0.2 0.0 translate intersect union "
+     "m plane 0.0 -1.4 0.0 translate union", (160, 120)),
+])
+def test_bound_volumes_do_not_change_results(gmlrt, oracle, label, scene, size):
+    light = "0.0 -1.0 0.0 point 1.0 1.0 1.0 point light /l "
+    text = SURF + light + scene + ' /s 0.3 0.3 0.3 point [ l ] s 4 90.0 %d %d "x.ppm" render' % size
+    call = gmlrt.Program(text=text).calls[0]
+    n_bounds = int(np.frombuffer(call.blob, dtype=np.uint32, count=12)[11])
+    assert n_bounds >= 3
+    img, f64, st = gmlrt.render(call, want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print(label, "bounds=%d differing=%d max=%d" % (n_bounds, ndiff, maxd), st.as_dict())
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert np.abs(f64 - ref64).max() <= 1e-9
+    assert st.rays_shadow > 0 and st.rays_reflect > 0
