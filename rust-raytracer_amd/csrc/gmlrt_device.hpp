@@ -43,6 +43,11 @@ struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags),
 };
 static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
 std::vector<uint8_t> derive_stream_program(const void* blob);
+// Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h), one per distinct
+// (code, constants) pair among the leaves; leaf_surf[leaf] = index of the leaf's first
+// record, or kNoSurfProg for a constant surface.
+constexpr uint32_t kNoSurfProg = 0xFFFFFFFFu;
+std::vector<uint8_t> derive_surface_stream(const void* blob, std::vector<uint32_t>* leaf_surf);
 
 // Device-resident copy of one scene blob plus the per-device scratch the render
 // kernel needs (per-ray event stacks, shading contexts, counters).
@@ -53,6 +58,8 @@ struct DeviceScene {
   void* d_prog = nullptr;       // derived program (record stream)
   uint32_t n_prog = 0;          // its size in bytes
   uint32_t n_vm_regs = 0;       // registers the scene's surface bytecode uses
+  void* d_surf = nullptr;       // expanded surface programs
+  void* d_leaf_surf = nullptr;  // u32 per leaf: first record of its program
   gmlrt_blob_header hdr{};
   // workspace, grown on demand and kept for the life of the handle
   void* d_ev_dist = nullptr;

@@ -39,7 +39,7 @@ constexpr uint32_t kFaceShift = 20;
 constexpr uint32_t kOrigExit = 1u << 23;  // the primitive produced this event as an Exit
 constexpr uint32_t kCurExit = 1u << 24;   // current type after operator switches
 constexpr uint32_t kHitAny = 1u << 31;    // set in the meta word handed to after_traversal: the ray hit something
-constexpr int kCtxFixed = 27;             // f64 fields of the shading context before the bounce stack
+constexpr int kCtxFixed = 24;             // f64 fields of the shading context before the bounce stack
 constexpr int kCtxPerLevel = 7;
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
@@ -74,6 +74,7 @@ struct KArgs {
   uint32_t ctx_fields;
   uint32_t n_vm_fast;    // surface-bytecode registers kept in LDS (the rest live in the context record)
   uint32_t vm_lds_off;   // byte offset of that LDS region (after the operand-stack lengths)
+  uint32_t lds_ctx;      // 1: the region also holds the hot fields of the shading context
   unsigned int* next_slot;
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
@@ -96,6 +97,8 @@ struct ShadeArgs {
   const gmlrt_light* lights;
   const uint64_t* code;
   const uint64_t* consts;
+  const uint32_t* leaf_surf;   // per leaf: first record of its expanded surface program
+  const SurfInstr* surf_prog;  // expanded surface programs
   unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
 };
 
@@ -441,7 +444,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- then the per-ray bookkeeping, out of line
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;)
     if (st_kind(S.st) != kIdle) {
-      S = after_traversal(S, h.dist, h.any ? (h.meta | kHitAny) : 0u, shade_args, ctx, vm_fast);
+      const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
+      if (A.lds_ctx) S = after_traversal<true>(S, h.dist, hm, shade_args, ctx, vm_fast);
+      else S = after_traversal<false>(S, h.dist, hm, shade_args, ctx, vm_fast);
       n_shadow += (S.st >> 24) & 1u;
       n_reflect += (S.st >> 25) & 1u;
       n_hits += (S.st >> 26) & 1u;
@@ -527,6 +532,14 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     out->n_vm_regs = H.n_code_words ? (top & (GMLRT_SURF_MAX_REGS - 1)) + 1 : 0;
     if (top >= GMLRT_SURF_MAX_REGS) out->n_vm_regs = GMLRT_SURF_MAX_REGS;
   }
+  {
+    std::vector<uint32_t> leaf_surf;
+    std::vector<uint8_t> surf = derive_surface_stream(blob, &leaf_surf);
+    HIP_TRY(hipMalloc(&out->d_surf, surf.size()));
+    HIP_TRY(hipMemcpy(out->d_surf, surf.data(), surf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&out->d_leaf_surf, leaf_surf.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(out->d_leaf_surf, leaf_surf.data(), leaf_surf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&out->d_counters, 512));
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
@@ -541,6 +554,8 @@ void dev_scene_destroy(DeviceScene* s) {
   if (hipSetDevice(s->device) != hipSuccess) return;
   (void)hipFree(s->d_blob);
   (void)hipFree(s->d_prog);
+  (void)hipFree(s->d_surf);
+  (void)hipFree(s->d_leaf_surf);
   (void)hipFree(s->d_ev_dist);
   (void)hipFree(s->d_ev_meta);
   (void)hipFree(s->d_ctx);
@@ -619,7 +634,16 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     const size_t room = per_block > lens_bytes + 1024 ? (per_block - lens_bytes - 1024) / ((size_t)kBlock * 8) : 0;
     if (n_vm_fast > room) n_vm_fast = room;
   }
-  const size_t lds_bytes = lens_bytes + n_vm_fast * kBlock * sizeof(uint64_t);
+  // With room for all of them the hot context fields go to LDS as well, into the same region.
+  const size_t hot_bytes = (size_t)kHotFields * kBlock * sizeof(double);
+  {
+    const size_t per_block = (size_t)prop.sharedMemPerBlock < (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu
+                                 ? (size_t)prop.sharedMemPerBlock
+                                 : (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu;
+    A.lds_ctx = lens_bytes + hot_bytes <= per_block ? 1u : 0u;
+  }
+  if (A.lds_ctx) n_vm_fast = s->n_vm_regs < (uint32_t)kHotFields ? s->n_vm_regs : (uint32_t)kHotFields;
+  const size_t lds_bytes = lens_bytes + (A.lds_ctx ? hot_bytes : n_vm_fast * kBlock * sizeof(uint64_t));
   A.n_vm_fast = (uint32_t)n_vm_fast;
   A.vm_lds_off = (uint32_t)lens_bytes;
   uint64_t grid = (uint64_t)prop.multiProcessorCount * (uint64_t)blocks_per_cu;
@@ -680,6 +704,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.lights = d_lights;
   SA.code = d_code;
   SA.consts = d_consts;
+  SA.leaf_surf = (const uint32_t*)s->d_leaf_surf;
+  SA.surf_prog = (const SurfInstr*)s->d_surf;
 #ifdef GMLRT_DIAG
   unsigned long long* d_diag_waves = nullptr;
   HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * 8 * sizeof(unsigned long long)));

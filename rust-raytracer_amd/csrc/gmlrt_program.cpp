@@ -24,7 +24,11 @@
 #include <stdexcept>
 #include <vector>
 
+#include <map>
+
 #include "gmlrt_device.hpp"
+#include "gmlrt_scene.hpp"
+#include "gmlrt_surface_vm.h"
 
 namespace gmlrt {
 
@@ -184,6 +188,30 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
   put_small(kRecEnd, 0);
   if (S.bytes.size() >= 0xFFFFFFF0ull) throw std::runtime_error("derived program too large");
   return S.bytes;
+}
+
+std::vector<uint8_t> derive_surface_stream(const void* blob, std::vector<uint32_t>* leaf_surf) {
+  gmlrt_blob_header H;
+  std::memcpy(&H, blob, sizeof(H));
+  const uint8_t* base = (const uint8_t*)blob;
+  const gmlrt_leaf* leaves = (const gmlrt_leaf*)(base + H.off_leaves);
+  const uint64_t* code = (const uint64_t*)(base + H.off_code);
+  const uint64_t* consts = (const uint64_t*)(base + H.off_consts);
+  std::vector<uint8_t> out;
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t> seen;
+  leaf_surf->assign(H.n_leaves, kNoSurfProg);
+  for (uint32_t i = 0; i < H.n_leaves; i++) {
+    if (leaves[i].surf_code == GMLRT_SURF_CONST) continue;
+    const auto key = std::make_pair(leaves[i].surf_code, leaves[i].surf_const);
+    auto it = seen.find(key);
+    if (it == seen.end()) {
+      it = seen.emplace(key, (uint32_t)(out.size() / sizeof(SurfInstr))).first;
+      expand_surface(code + key.first, consts + key.second, out);
+    }
+    (*leaf_surf)[i] = it->second;
+  }
+  if (out.empty()) out.resize(sizeof(SurfInstr), 0);  // a lone END record: never run, keeps the buffer non-empty
+  return out;
 }
 
 }  // namespace gmlrt

@@ -498,14 +498,47 @@ SurfaceProgram compile_surface(const gml::Value& closure) {
   return sp;
 }
 
+void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+  if (p.constant) {
+    for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
+    return;
+  }
+  uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
+  surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R);
+}
+
+void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<uint8_t>& out) {
+  for (size_t pc = 0;; pc++) {
+    const uint64_t w = code[pc];
+    SurfInstr I;
+    std::memset(&I, 0, sizeof(I));
+    const uint32_t op = (uint32_t)(w & 0xFF);
+    I.head = (uint32_t)(w & 0xFFFF);
+    const uint32_t x[3] = {(uint32_t)((w >> 16) & 0xFFFF), (uint32_t)((w >> 32) & 0xFFFF), (uint32_t)((w >> 48) & 0xFFFF)};
+    uint64_t* slot[3] = {&I.a, &I.b, &I.c};
+    const uint32_t imm[3] = {GMLRT_SI_IMM_A, GMLRT_SI_IMM_B, GMLRT_SI_IMM_C};
+    if (op != GMLRT_SOP_END)
+      for (int k = 0; k < 3; k++) {
+        if (x[k] & 0x8000u) { *slot[k] = consts[x[k] & 0x7FFFu]; I.head |= imm[k]; }
+        else *slot[k] = x[k] & (GMLRT_SURF_MAX_REGS - 1);
+      }
+    const uint8_t* b = (const uint8_t*)&I;
+    out.insert(out.end(), b, b + sizeof(I));
+    if (op == GMLRT_SOP_END) break;
+  }
+}
+
 void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
   if (p.constant) {
     for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
     return;
   }
-  uint64_t regs[GMLRT_SURF_MAX_REGS];
-  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1};
-  surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R);
+  std::vector<uint8_t> rec;
+  expand_surface(p.code.data(), p.consts.data(), rec);
+  uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
+  surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, out, R);
 }
 
 // ============================================================== flattening

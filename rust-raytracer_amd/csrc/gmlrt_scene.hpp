@@ -29,9 +29,17 @@ struct SurfaceProgram {
 // control flow.  Throws UnsupportedSurface / gml::GmlError.
 SurfaceProgram compile_surface(const gml::Value& closure);
 
-// Reference interpreter of the bytecode on the host (used by unit tests to check
-// the compiler against the tree-walking evaluator; the device has its own copy).
+// Host runs of the bytecode (used by unit tests to check the compiler against the
+// tree-walking evaluator).  run_surface_program goes the way the device does: it
+// expands the words into records with inline constants and interprets those;
+// run_surface_words interprets the blob's words directly.
 void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+
+// Expansion of one (code, constants) pair: appends 32-byte SurfInstr records (END
+// included) to `out`.  `code` points at the program's first word, `consts` at the
+// surface's first constant.
+void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<uint8_t>& out);
 
 // Flattens one render call.  Throws UnsupportedSurface / gml::GmlError.
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc);

@@ -5,93 +5,104 @@
 // either the next ray to traverse in the lane state or an idle lane with its pixel
 // written.  It runs once per traced ray, out of line, so that the traversal loop
 // keeps a small register footprint.  Values that must survive the next traversal
-// are parked in the lane's context record in device memory; the code is laid out
-// so that each path does one batch of loads from it, not a chain of them.
+// are parked in the lane's context record.  The function is written so that few
+// values are live at any point (each phase stores what it produced and the next
+// one loads what it needs): what it keeps in registers beyond the caller-saved set
+// costs a save and a restore at every call.
 
-// Context fields (f64 each, field-major: field f of this lane at ctx[f * 64]).
-#define CTX(f) ctx[(size_t)(f) * kWave]
-__device__ inline V3 ctx_get3(const double* ctx, int f) { return {CTX(f), CTX(f + 1), CTX(f + 2)}; }
-__device__ inline void ctx_set3(double* ctx, int f, V3 v) { CTX(f) = v.x; CTX(f + 1) = v.y; CTX(f + 2) = v.z; }
-enum { F_POS = 0, F_NRM = 3, F_SC = 6, F_KD = 9, F_KS = 10, F_N = 11, F_C = 12, F_DIFF = 15, F_SPEC = 18,
-       F_RPOS = 21, F_RDIR = 24 };
+// The lane's context record.  "Hot" fields are read and written around every shadow
+// ray; when the block's LDS has room for them they live there (kLds), lane-strided, in
+// the region the surface bytecode's registers use while a hit is being shaded (the two
+// never hold live data at the same time).  Otherwise they are the first fields of the
+// lane's record in device memory.  "Cold" fields always live in that record.
+//   hot field f of this lane:  kLds ? lds[f * 256] : ctx[f * 64]      cold: ctx[f * 64]
+enum { H_POS = 0, H_NRM = 3, H_SC = 6, H_KD = 9, H_KS = 10, H_N = 11, H_DIFF = 12, H_SPEC = 15, kHotFields = 18,
+       C_RPOS = 18, C_RDIR = 21 };
+static_assert(kCtxFixed == 24, "cold fields end where the parked bounce records begin");
+#define COLD(f) ctx[(size_t)(f) * kWave]
+#define HOT(f) hot[(size_t)(f) * kHotStride]
+__device__ inline V3 cold_get3(const double* ctx, int f) { return {COLD(f), COLD(f + 1), COLD(f + 2)}; }
+__device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD(f + 1) = v.y; COLD(f + 2) = v.z; }
+#define HOT_GET3(f) V3{HOT(f), HOT((f) + 1), HOT((f) + 2)}
+#define HOT_SET3(f, v) do { const V3 v_ = (v); HOT(f) = v_.x; HOT((f) + 1) = v_.y; HOT((f) + 2) = v_.z; } while (0)
 
 // The traversal result travels as two scalars (distance; meta with kHitAny set when
 // there is a hit): together with the lane state an aggregate would exceed what the
 // calling convention passes in registers and go through the stack.
-__device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta,
+template <bool kLds>
+__device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
                                                   const ShadeArgs* __restrict__ SA_v, double* __restrict__ ctx_v,
                                                   uint64_t* __restrict__ vm_fast_v) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
   double* __restrict__ ctx = global_space(ctx_v);
-  const ScenePtrs P = {const_space(wave_uniform(SA->leaves)), nullptr, const_space(wave_uniform(SA->lights)),
-                       const_space(wave_uniform(SA->code)), const_space(wave_uniform(SA->consts))};
-  const Hit h = {(h_meta & kHitAny) != 0, h_dist, h_meta & ~kHitAny, false};
+  constexpr size_t kHotStride = kLds ? (size_t)kBlock : (size_t)kWave;
+  double* hot;
+  if constexpr (kLds) hot = (double*)(GMLRT_AS(3) double*)(uintptr_t)vm_fast_v;
+  else hot = ctx;
+  const gmlrt_leaf* __restrict__ leaves = const_space(wave_uniform(SA->leaves));
+  const gmlrt_light* __restrict__ lights = const_space(wave_uniform(SA->lights));
+  const bool h_any = (h_meta_any & kHitAny) != 0;
+  const uint32_t h_meta = h_meta_any & ~kHitAny;
   int kind = st_kind(S.st);
   int level = (int)((S.st >> 2) & 0x7FFu);
   uint32_t li = (S.st >> 13) & 0x7FFu;
   uint32_t events = 0;
   const uint32_t n_lights = SA->n_lights;
-
   bool advance = false, finish = false;
-  V3 C = {0.0, 0.0, 0.0};  // value of trace() at `level` when finish is set
-  // the shading point: filled by either path below when `advance` is set
-  V3 pos = {0, 0, 0}, normal = {0, 0, 0}, sc = {0, 0, 0}, diff = {0, 0, 0}, spec = {0, 0, 0};
-  double kd = 0.0, ks = 0.0;
-  bool fresh = false;       // the point was shaded in this call: its ambient term and view ray are in registers
-  V3 c_amb = {0, 0, 0};
 
   DIAG(unsigned long long tq0 = __builtin_readcyclecounter(), tq1, tq2, tq3, tq4, tq5, tq6;)
   // ---- raytracer.rs:58-62: geometry of a view ray's hit in the primitive's object space
   bool shade = false;
-  const gmlrt_leaf* L = P.leaves;
-  uint32_t type = 0, mycode = GMLRT_SURF_CONST, myconst = 0;
+  uint32_t mysurf = kNoSurfProg;
   int face = 0;
   double u = 0.0, v = 0.0;
   V3 opos = {0, 0, 0};
   if (kind == kView) {
-    if (!h.any || (h.meta & kCurExit)) {
+    if (!h_any || (h_meta & kCurExit)) {
       finish = true;  // raytracer.rs:55-57, 108-110
     } else {
       shade = true;
-      L = P.leaves + (h.meta & kLeafMask);
-      face = (int)((h.meta >> kFaceShift) & 7u);
-      type = L->type;
-      mycode = L->surf_code;
-      myconst = L->surf_const;
+      const gmlrt_leaf* L = leaves + (h_meta & kLeafMask);
+      face = (int)((h_meta >> kFaceShift) & 7u);
+      const uint32_t type = L->type;
+      mysurf = const_space(wave_uniform(SA->leaf_surf))[h_meta & kLeafMask];
       double scale; V3 rd, rp;
       to_object(L->inv_m, S.o, S.d, scale, rd, rp);
       PrimHit ph = isect_prim(type, rp, rd);
-      const double od = (h.meta & kOrigExit) ? ph.tB : ph.tA;
+      const double od = (h_meta & kOrigExit) ? ph.tB : ph.tA;
       opos = vadd(rp, vmul(rd, od));
       prim_uv(type, face, opos, u, v);
+      // the view ray is needed again for the highlight and the bounce; S is free from here on
+      cold_set3(ctx, C_RPOS, S.o);
+      cold_set3(ctx, C_RDIR, S.d);
     }
   }
 
-  // ---- raytracer.rs:63: the surface function.  Each distinct (program, constants) pair among
-  // the wave's hits is interpreted once, by all lanes in uniform control flow (so the
-  // bytecode is fetched with scalar loads); a lane keeps the result of its own pair.
-  // Lanes without a hit run along on zeros; the bytecode has no trapping operation.
-  double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // ---- raytracer.rs:63: the surface function.  Each distinct program among the wave's hits
+  // is interpreted once, by all lanes in uniform control flow (so its records come by
+  // scalar loads); a lane keeps the result of its own program.  Lanes without a hit run
+  // along on zeros without storing anything; the bytecode has no trapping operation.
   DIAG(tq1 = __builtin_readcyclecounter();)
+  double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   {
     typedef GMLRT_AS(3) uint64_t* LdsP;
     typedef GMLRT_AS(1) uint64_t* GlobalP;
-    typedef const GMLRT_AS(4) uint64_t* ConstP;
+    typedef const GMLRT_AS(4) SurfInstr* ProgP;
     const VmRegs<LdsP, GlobalP> R = {
         (LdsP)(uintptr_t)vm_fast_v, (uint32_t)kBlock, SA->n_vm_fast,
-        (GlobalP)(uintptr_t)(ctx_v + (size_t)(SA->ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), (uint32_t)kWave};
-    const ConstP code = (ConstP)(uintptr_t)P.code, consts = (ConstP)(uintptr_t)P.consts;
+        (GlobalP)(uintptr_t)(ctx_v + (size_t)(SA->ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), (uint32_t)kWave,
+        shade};  // the region holds live context fields of the lanes that are not shading a hit
+    const ProgP progs = (ProgP)(uintptr_t)wave_uniform(SA->surf_prog);
     const bool all_fast = SA->vm_all_fast != 0;
-    bool need = shade && mycode != GMLRT_SURF_CONST;
+    bool need = shade && mysurf != kNoSurfProg;
     unsigned long long todo = __ballot(need);
     while (todo) {
       const int src = __builtin_ctzll(todo);
-      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mycode, src);
-      const uint32_t curk = (uint32_t)__builtin_amdgcn_readlane((int)myconst, src);
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mysurf, src);
       double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (all_fast) surface_vm<true>(code + cur, consts + curk, (int64_t)face, u, v, t6, R);
-      else surface_vm<false>(code + cur, consts + curk, (int64_t)face, u, v, t6, R);
-      if (need && mycode == cur && myconst == curk) {
+      if (all_fast) surface_stream_vm<true>(progs + cur, (int64_t)face, u, v, t6, R);
+      else surface_stream_vm<false>(progs + cur, (int64_t)face, u, v, t6, R);
+      if (need && mysurf == cur) {
 #pragma unroll
         for (int q = 0; q < 6; q++) s6[q] = t6[q];
         need = false;
@@ -102,66 +113,54 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
 
   DIAG(tq2 = __builtin_readcyclecounter();)
   if (shade) {
-    {
-      if (mycode == GMLRT_SURF_CONST) {
-        const uint64_t* kc = P.consts + myconst;
+    // ---- raytracer.rs:63-68: surface result, position and normal in world space
+    const gmlrt_leaf* L = leaves + (h_meta & kLeafMask);
+    if (mysurf == kNoSurfProg) {
+      const uint64_t* kc = const_space(wave_uniform(SA->consts)) + L->surf_const;
 #pragma unroll
-        for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
-      }
-      sc = {s6[0], s6[1], s6[2]};
-      kd = s6[3];
-      ks = s6[4];
-      c_amb = vmul(vcmul({SA->amb[0], SA->amb[1], SA->amb[2]}, sc), kd);  // get_ambient
-      // ---- raytracer.rs:64-68: position and normal in world space
-      const double* m = L->m;
-      pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3], m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
-             m[8] * opos.x + m[9] * opos.y + m[10] * opos.z + m[11]};
-      const V3 no = prim_normal(type, face, opos);
-      const double* im = L->inv_m;  // transform_normal: transpose(inv_m) * n  (transform.rs:34-36)
-      V3 nw = {im[0] * no.x + im[4] * no.y + im[8] * no.z, im[1] * no.x + im[5] * no.y + im[9] * no.z,
-               im[2] * no.x + im[6] * no.y + im[10] * no.z};
-      normal = vnormalize(nw);
-      if (((h.meta & kCurExit) != 0) != ((h.meta & kOrigExit) != 0)) normal = vneg(normal);
-      ctx_set3(ctx, F_POS, pos);
-      ctx_set3(ctx, F_NRM, normal);
-      ctx_set3(ctx, F_SC, sc);
-      CTX(F_KD) = kd; CTX(F_KS) = ks; CTX(F_N) = s6[5];
-      ctx_set3(ctx, F_C, c_amb);
-      ctx_set3(ctx, F_RPOS, S.o);
-      ctx_set3(ctx, F_RDIR, S.d);
-      fresh = true;
-      li = 0;
-      events |= kStHit;
-      advance = true;
+      for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
     }
+    HOT(H_SC) = s6[0]; HOT(H_SC + 1) = s6[1]; HOT(H_SC + 2) = s6[2];
+    HOT(H_KD) = s6[3]; HOT(H_KS) = s6[4]; HOT(H_N) = s6[5];
+    HOT_SET3(H_DIFF, (V3{0.0, 0.0, 0.0}));
+    HOT_SET3(H_SPEC, (V3{0.0, 0.0, 0.0}));
+    const double* m = L->m;
+    const V3 pos = {m[0] * opos.x + m[1] * opos.y + m[2] * opos.z + m[3], m[4] * opos.x + m[5] * opos.y + m[6] * opos.z + m[7],
+                    m[8] * opos.x + m[9] * opos.y + m[10] * opos.z + m[11]};
+    HOT_SET3(H_POS, pos);
+    const V3 no = prim_normal(L->type, face, opos);
+    const double* im = L->inv_m;  // transform_normal: transpose(inv_m) * n  (transform.rs:34-36)
+    const V3 nw = {im[0] * no.x + im[4] * no.y + im[8] * no.z, im[1] * no.x + im[5] * no.y + im[9] * no.z,
+                   im[2] * no.x + im[6] * no.y + im[10] * no.z};
+    V3 normal = vnormalize(nw);
+    if (((h_meta & kCurExit) != 0) != ((h_meta & kOrigExit) != 0)) normal = vneg(normal);
+    HOT_SET3(H_NRM, normal);
+    li = 0;
+    events |= kStHit;
+    advance = true;
   }
   DIAG(tq3 = __builtin_readcyclecounter();)
   if (kind == kShadow) {
     // ---- raytracer.rs:76-93: is light `li` visible along the shadow ray just traced
-    const gmlrt_light& l = P.lights[li];
-    pos = ctx_get3(ctx, F_POS);
-    normal = ctx_get3(ctx, F_NRM);
-    sc = ctx_get3(ctx, F_SC);
-    kd = CTX(F_KD);
-    ks = CTX(F_KS);
-    const double sn = CTX(F_N);
-    diff = ctx_get3(ctx, F_DIFF);
-    spec = ctx_get3(ctx, F_SPEC);
-    const V3 raypos = ctx_get3(ctx, F_RPOS);
+    const gmlrt_light& l = lights[li];
+    const V3 pos = HOT_GET3(H_POS);
     V3 ldir; bool has_ld; double ld;
     light_direction(l, pos, ldir, has_ld, ld);
-    bool lit = !h.any;
-    if (!lit && has_ld && ld < h.dist) lit = true;
+    bool lit = !h_any;
+    if (!lit && has_ld && ld < h_dist) lit = true;
     if (lit) {
+      const V3 normal = HOT_GET3(H_NRM);
       const double df = vdot(normal, ldir);
-      const V3 ic = vcmul(sc, light_intensity(l, pos));
-      if (kd > 0.0) diff = vadd(diff, vmul(ic, df));
-      if (ks > 0.0) {
+      const V3 ic = vcmul(HOT_GET3(H_SC), light_intensity(l, pos));
+      if (HOT(H_KD) > 0.0) HOT_SET3(H_DIFF, vadd(HOT_GET3(H_DIFF), vmul(ic, df)));
+      if (HOT(H_KS) > 0.0) {
         // get_specular, raytracer.rs:34-42
+        const V3 raypos = cold_get3(ctx, C_RPOS);
         const V3 halfway = vnormalize(vadd(ldir, vnormalize(vsub(raypos, pos))));
         const double sp = vdot(normal, halfway);
-        if (sp > 0.0) spec = vadd(spec, vmul(ic, pow(sp, sn)));
-        else spec = vadd(spec, {0.0, 0.0, 0.0});
+        V3 add = {0.0, 0.0, 0.0};
+        if (sp > 0.0) add = vmul(ic, pow(sp, HOT(H_N)));
+        HOT_SET3(H_SPEC, vadd(HOT_GET3(H_SPEC), add));
       }
     }
     li++;
@@ -169,16 +168,15 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
   }
 
   DIAG(tq4 = __builtin_readcyclecounter();)
+  V3 C = {0.0, 0.0, 0.0};  // value of trace() at `level` when finish is set
   if (advance) {
     // ---- raytracer.rs:69-74: next light that faces the surface gets a shadow ray
+    const V3 pos = HOT_GET3(H_POS), normal = HOT_GET3(H_NRM);
     bool spawned = false;
     while (li < n_lights) {
       V3 ldir; bool has_ld; double ld;
-      light_direction(P.lights[li], pos, ldir, has_ld, ld);
+      light_direction(lights[li], pos, ldir, has_ld, ld);
       if (vdot(normal, ldir) > 0.0) {
-        // the accumulators wait in memory while the shadow ray is traced
-        ctx_set3(ctx, F_DIFF, diff);
-        ctx_set3(ctx, F_SPEC, spec);
         S.o = vadd(pos, vmul(ldir, 1e-7));
         S.d = ldir;
         kind = kShadow;
@@ -190,16 +188,18 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     }
     if (!spawned) {
       // ---- raytracer.rs:96-107
-      const V3 c0 = fresh ? c_amb : ctx_get3(ctx, F_C);
-      const V3 c = vadd(c0, vadd(vmul(diff, kd), vmul(spec, ks)));
+      const V3 sc = HOT_GET3(H_SC);
+      const double kd = HOT(H_KD), ks = HOT(H_KS);
+      const V3 c0 = vmul(vcmul({SA->amb[0], SA->amb[1], SA->amb[2]}, sc), kd);  // get_ambient, raytracer.rs:30-32
+      const V3 c = vadd(c0, vadd(vmul(HOT_GET3(H_DIFF), kd), vmul(HOT_GET3(H_SPEC), ks)));
       if (ks > 0.0 && (SA->depth - level) > 0) {
-        const V3 raydir = fresh ? S.d : ctx_get3(ctx, F_RDIR);
+        const V3 raydir = cold_get3(ctx, C_RDIR);
         const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
         // park (c, sc, ks) until the bounce below returns
         const int f = kCtxFixed + level * kCtxPerLevel;
-        ctx_set3(ctx, f, c);
-        ctx_set3(ctx, f + 3, sc);
-        CTX(f + 6) = ks;
+        cold_set3(ctx, f, c);
+        cold_set3(ctx, f + 3, sc);
+        COLD(f + 6) = ks;
         S.o = vadd(pos, vmul(refl, 1e-7));
         S.d = refl;
         kind = kView;
@@ -217,9 +217,9 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
     for (int lv = level - 1; lv >= 0; lv--) {
       const int f = kCtxFixed + lv * kCtxPerLevel;
-      const V3 c = ctx_get3(ctx, f);
-      const V3 psc = ctx_get3(ctx, f + 3);
-      const double pks = CTX(f + 6);
+      const V3 c = cold_get3(ctx, f);
+      const V3 psc = cold_get3(ctx, f + 3);
+      const double pks = COLD(f + 6);
       C = vadd(c, vmul(vcmul(C, psc), pks));
     }
     const size_t oidx = (size_t)S.pix * 3;

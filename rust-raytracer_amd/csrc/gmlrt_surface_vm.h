@@ -63,6 +63,7 @@ struct VmRegs {
   uint32_t fast_stride, n_fast;
   SlowP slow;
   uint32_t slow_stride;
+  bool writable;  // false: this lane only runs along with its wave and must not touch the storage
 };
 // kAllFast: the caller guarantees that every register the program names is below n_fast.
 template <bool kAllFast, class RegsT>
@@ -73,6 +74,7 @@ GMLRT_HD uint64_t vm_get(const RegsT& R, uint32_t i) {
 }
 template <bool kAllFast, class RegsT>
 GMLRT_HD void vm_set(const RegsT& R, uint32_t i, uint64_t v) {
+  if (!R.writable) return;
   if (kAllFast || i < R.n_fast) R.fast[(size_t)i * R.fast_stride] = v;
   else R.slow[(size_t)i * R.slow_stride] = v;
 }
@@ -136,6 +138,93 @@ GMLRT_HD void surface_vm(CodeP code, ConstP consts, int64_t face, double u, doub
     vm_set<kAllFast>(R, dst & (GMLRT_SURF_MAX_REGS - 1), res);
   }
 #undef OPND
+}
+
+// ---- expanded form.  What the device interprets is not the blob's word code but an
+// expansion of it, one 32-byte record per instruction with the constants inline, made
+// once per distinct (code, constants) pair when a scene is uploaded: one wave-uniform
+// load brings everything an instruction needs, and the record after it is requested
+// before the current one executes.
+struct SurfInstr {
+  uint32_t head;  // op in bits 7..0, dst in 15..8, bit 16/17/18: a/b/c is an immediate (else a register index)
+  uint32_t pad;
+  uint64_t a, b, c;
+};
+#define GMLRT_SI_IMM_A 0x10000u
+#define GMLRT_SI_IMM_B 0x20000u
+#define GMLRT_SI_IMM_C 0x40000u
+
+// field by field: a struct cannot be copied out of an address-space-qualified pointer
+template <class ProgP>
+GMLRT_HD SurfInstr vm_fetch(ProgP prog, uint32_t pc) {
+  SurfInstr I;
+  I.head = prog[pc].head;
+  I.pad = 0;
+  I.a = prog[pc].a;
+  I.b = prog[pc].b;
+  I.c = prog[pc].c;
+  return I;
+}
+
+template <bool kAllFast, class ProgP, class RegsT>
+GMLRT_HD void surface_stream_vm(ProgP prog, int64_t face, double u, double v, double out[6], const RegsT R) {
+  vm_set<kAllFast>(R, 0, (uint64_t)face);
+  vm_set<kAllFast>(R, 1, vm_from_f64(u));
+  vm_set<kAllFast>(R, 2, vm_from_f64(v));
+  SurfInstr I = vm_fetch(prog, 0);
+  for (uint32_t pc = 1;; pc++) {
+    const uint32_t head = I.head;
+    const uint32_t op = head & 0xFFu;
+    if (op == GMLRT_SOP_END) break;
+    const SurfInstr next = vm_fetch(prog, pc);  // always exists: the program ends with an END record
+    const uint32_t dst = (head >> 8) & 0xFFu;
+    const uint64_t a = (head & GMLRT_SI_IMM_A) ? I.a : vm_get<kAllFast>(R, (uint32_t)I.a);
+    const uint64_t b = (head & GMLRT_SI_IMM_B) ? I.b : vm_get<kAllFast>(R, (uint32_t)I.b);
+    const double fa = vm_as_f64(a), fb = vm_as_f64(b);
+    const int64_t ia = (int64_t)a, ib = (int64_t)b;
+    uint64_t res = 0;
+    switch (op) {
+      case GMLRT_SOP_MOV: res = a; break;
+      case GMLRT_SOP_ADDI: res = a + b; break;
+      case GMLRT_SOP_SUBI: res = a - b; break;
+      case GMLRT_SOP_MULI: res = a * b; break;
+      case GMLRT_SOP_DIVI: res = (uint64_t)vm_divi(ia, ib); break;
+      case GMLRT_SOP_MODI: res = (uint64_t)vm_modi(ia, ib); break;
+      case GMLRT_SOP_EQI: res = ia == ib; break;
+      case GMLRT_SOP_LESSI: res = ia < ib; break;
+      case GMLRT_SOP_REAL: res = vm_from_f64((double)ia); break;
+      case GMLRT_SOP_FLOOR: res = (uint64_t)vm_floor_i64(fa); break;
+      case GMLRT_SOP_ADDF: res = vm_from_f64(fa + fb); break;
+      case GMLRT_SOP_SUBF: res = vm_from_f64(fa - fb); break;
+      case GMLRT_SOP_MULF: res = vm_from_f64(fa * fb); break;
+      case GMLRT_SOP_DIVF: res = vm_from_f64(fa / fb); break;
+      case GMLRT_SOP_EQF: res = fa == fb; break;
+      case GMLRT_SOP_LESSF: res = fa < fb; break;
+      case GMLRT_SOP_SQRT: res = vm_from_f64(sqrt(fa)); break;
+      case GMLRT_SOP_FRAC: res = vm_from_f64(vm_frac(fa)); break;
+      case GMLRT_SOP_CLAMPF: res = vm_from_f64(vm_clampf(fa)); break;
+      case GMLRT_SOP_SIN: res = vm_from_f64(vm_sin(fa)); break;
+      case GMLRT_SOP_COS: res = vm_from_f64(vm_cos(fa)); break;
+      case GMLRT_SOP_ASIN: res = vm_from_f64(vm_to_degrees(asin(fa))); break;
+      case GMLRT_SOP_ACOS: res = vm_from_f64(vm_to_degrees(acos(fa))); break;
+      case GMLRT_SOP_SELECT: {
+        const uint64_t c = (head & GMLRT_SI_IMM_C) ? I.c : vm_get<kAllFast>(R, (uint32_t)I.c);
+        res = a ? b : c;
+        break;
+      }
+      case GMLRT_SOP_OUT: {
+        const uint64_t c = (head & GMLRT_SI_IMM_C) ? I.c : vm_get<kAllFast>(R, (uint32_t)I.c);
+        const double fc = vm_as_f64(c);
+        if (dst == 0) { out[0] = fa; out[1] = fb; out[2] = fc; }
+        else if (dst == 3) { out[3] = fa; out[4] = fb; out[5] = fc; }
+        I = next;
+        continue;
+      }
+      default: break;
+    }
+    vm_set<kAllFast>(R, dst & (GMLRT_SURF_MAX_REGS - 1), res);
+    I = next;
+  }
 }
 
 }  // namespace gmlrt

@@ -164,6 +164,9 @@ int th_surface_compare(const char* path, int idx, int samples, unsigned seed, do
         ev.call_surface(*lf.second, face, uu, vv, &col, &kd, &ks, &n);
         double o[6];
         gmlrt::run_surface_program(it->second, face, uu, vv, o);
+        double o2[6];
+        gmlrt::run_surface_words(it->second, face, uu, vv, o2);  // both interpreters must agree bit for bit
+        if (std::memcmp(o, o2, sizeof(o)) != 0) stats[2] = INFINITY;
         const double ref[6] = {col[0], col[1], col[2], kd, ks, n};
         for (int k = 0; k < 6; k++) {
           stats[0] += 1;
@@ -196,6 +199,9 @@ int th_surface_eval_text(const char* text, const char* var, long long face, doub
     *is_const = sp.constant;
     *n_code = (int)sp.code.size();
     gmlrt::run_surface_program(sp, face, u, v, got);
+    double got2[6];
+    gmlrt::run_surface_words(sp, face, u, v, got2);
+    if (std::memcmp(got, got2, sizeof(got2)) != 0) { put("the two bytecode interpreters disagree", err, errlen); return -1; }
     return 0;
   } catch (gmlrt::UnsupportedSurface& e) {
     put(std::string("UNSUPPORTED ") + e.what(), err, errlen);
