@@ -21,7 +21,7 @@ struct ProgBound {   // 48 bytes
   uint32_t skip_to;  // byte offset of the first record after the bounded subtree
   double center[3];
   double radius2;
-  uint64_t pad;
+  double radius;
 };
 struct ProgBox {     // 64 bytes: the same as ProgBound with the subtree's box instead of its sphere
   uint32_t kind;

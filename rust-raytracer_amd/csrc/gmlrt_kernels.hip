@@ -296,6 +296,17 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
   return h;
 }
 
+// Measured on chess 4K depth 5 (Mrays/s): none 3384, TSTOP 3387, TSTOP+TMAX_CULL 3534, TMAX_CULL 3493;
+// an all-lanes-done test in front of every record cost more than it saved (3265).
+#ifndef GMLRT_TSTOP
+#define GMLRT_TSTOP 1
+#endif
+#ifndef GMLRT_TMAX_CULL
+#define GMLRT_TMAX_CULL 1
+#endif
+#ifndef GMLRT_TOP_EXIT
+#define GMLRT_TOP_EXIT 0
+#endif
 #include "gmlrt_traverse.hpp"
 
 // ---------------------------------------------------------------- lights (lights.rs:42-120)
@@ -333,11 +344,12 @@ __device__ inline uint8_t quantise(double p) {
   return (uint8_t)v;
 }
 
-// What a lane carries from one traversal to the next.  Kept to 56 bytes so that it
+// What a lane carries from one traversal to the next.  Kept to 60 bytes so that it
 // travels to and from the out-of-line code in registers (a larger struct would be
 // passed through the stack, i.e. scratch memory).
 struct LaneState {
   V3 o, d;       // ray to traverse
+  float t_stop;  // the traversal may stop at the first hit at or before this distance (-inf: never)
   uint32_t pix;  // output index (row-in-partition * w + x)
   uint32_t st;   // bits 1..0 RayKind, 12..2 bounce level, 23..13 light being tested,
                  // 24 / 25 / 26: after_traversal spawned a shadow ray / a bounce / shaded a hit
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   LaneState S;
   S.o = {0, 0, 0};
   S.d = {0, 0, 1};
+  S.t_stop = -__builtin_inff();
   S.pix = 0;
   S.st = kIdle;
   uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
@@ -420,6 +433,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
           S.o = {0.0, 0.0, -1.0};
           S.d = vnormalize(dir);
+          S.t_stop = -__builtin_inff();
           S.st = kView;  // level 0
           S.pix = yl * (uint32_t)A.w + x;
           n_primary++;
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          dg.lanes += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
 
     // ---- one scene traversal for whatever ray each lane holds
-    Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, evD, evM, lens, dg);
+    Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if (__ballot(h.redo)) {
       // a primitive right under the root's unions gave a span shorter than 1e-10: only the
       // full sweep knows whether it survives (primitives.rs:295-298)
@@ -731,9 +745,16 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       std::vector<unsigned long long> per_wave(lanes / kWave * 8);
       HIP_TRY(hipMemcpy(per_wave.data(), d_diag_waves, per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       (void)hipFree(d_diag_waves);
+      unsigned long long vm_runs = 0, vm_lanes = 0;
       for (int q = 0; q < 6; q++) dgv[10 + q] = 0;
-      for (size_t wv = 0; wv < lanes / kWave; wv++)
+      for (size_t wv = 0; wv < lanes / kWave; wv++) {
         for (int q = 0; q < 6; q++) dgv[10 + q] += per_wave[wv * 8 + q];
+        vm_runs += per_wave[wv * 8 + 6];
+        vm_lanes += per_wave[wv * 8 + 7];
+      }
+      std::fprintf(stderr, "[gmlrt diag] surface program runs %llu (%.2f per traversal), lanes wanting one %.1f per traversal\n",
+                   vm_runs, (double)vm_runs / ((double)dgv[3] > 0 ? (double)dgv[3] : 1.0),
+                   (double)vm_lanes / ((double)dgv[3] > 0 ? (double)dgv[3] : 1.0));
     }
     const double nt = (double)dgv[3] > 0 ? (double)dgv[3] : 1.0;
     std::fprintf(stderr,

@@ -126,6 +126,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
     r.skip_to = 0;  // patched when the subtree is complete
     for (int i = 0; i < 3; i++) r.center[i] = bounds[idx].center[i];
     r.radius2 = bounds[idx].radius * bounds[idx].radius;
+    r.radius = bounds[idx].radius;
     return S.put(&r, sizeof(r));
   };
   auto put_leaf = [&](uint32_t leaf, bool take) {

@@ -50,7 +50,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
   const uint32_t n_lights = SA->n_lights;
   bool advance = false, finish = false;
 
-  DIAG(unsigned long long tq0 = __builtin_readcyclecounter(), tq1, tq2, tq3, tq4, tq5, tq6;)
+  DIAG(unsigned long long tq0 = __builtin_readcyclecounter(), tq1, tq2, tq3, tq4, tq5, tq6, tq_runs = 0, tq_lanes = 0;)
   // ---- raytracer.rs:58-62: geometry of a view ray's hit in the primitive's object space
   bool shade = false;
   uint32_t mysurf = kNoSurfProg;
@@ -96,7 +96,9 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     const bool all_fast = SA->vm_all_fast != 0;
     bool need = shade && mysurf != kNoSurfProg;
     unsigned long long todo = __ballot(need);
+    DIAG(unsigned long long vm_runs = 0; const unsigned long long vm_lanes = (unsigned long long)__popcll(todo);)
     while (todo) {
+      DIAG(vm_runs++;)
       const int src = __builtin_ctzll(todo);
       const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mysurf, src);
       double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -109,6 +111,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       }
       todo = __ballot(need);
     }
+    DIAG(tq_runs = vm_runs; tq_lanes = vm_lanes;)
   }
 
   DIAG(tq2 = __builtin_readcyclecounter();)
@@ -179,6 +182,9 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       if (vdot(normal, ldir) > 0.0) {
         S.o = vadd(pos, vmul(ldir, 1e-7));
         S.d = ldir;
+        // all the light test will ask is whether the first hit lies at or before the light
+        // (any hit at all for a light at infinity); rounded down so that the float never exceeds it
+        S.t_stop = has_ld ? (float)(ld * (1.0 - 1e-6)) : __builtin_inff();
         kind = kShadow;
         events |= kStShadow;
         spawned = true;
@@ -202,6 +208,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
         COLD(f + 6) = ks;
         S.o = vadd(pos, vmul(refl, 1e-7));
         S.d = refl;
+        S.t_stop = -__builtin_inff();
         kind = kView;
         level++;
         events |= kStReflect;
@@ -238,7 +245,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
          unsigned long long* dq = global_space(wave_uniform(SA->diag_waves)) +
                                   ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * 8;
          dq[0] += tq1 - tq0; dq[1] += tq2 - tq1; dq[2] += tq3 - tq2; dq[3] += tq4 - tq3; dq[4] += tq5 - tq4;
-         dq[5] += tq6 - tq5;
+         dq[5] += tq6 - tq5; dq[6] += tq_runs; dq[7] += tq_lanes;
        })
   S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | events;
   return S;

@@ -6,10 +6,19 @@
 // wave-uniform address.  The tree of unions under the root keeps only the nearest
 // first Entry of its children (`best`); every other operator is evaluated with
 // lists exactly as intersect_general does.
+//
+// Two things cut a lane's work short without changing what its caller sees:
+// * a subtree whose bound cannot be reached before the lane's current `best` cannot
+//   supply a nearer Entry (an equal one loses the tie to the earlier candidate anyway);
+// * t_stop: the caller only wants to know whether the first hit lies at or before that
+//   distance (a shadow ray's test against its light, raytracer.rs:76-79); as soon as a
+//   lane has such a candidate it stops taking part, and bounds are skipped by the wave
+//   once no lane is left that needs them.  Camera and bounce rays pass -infinity.
 
 __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
-                                      uint32_t n_leaves, bool active, V3 o, V3 d, double* __restrict__ evD,
-                                      uint32_t* __restrict__ evM, uint16_t* __restrict__ lens, Diag& dg) {
+                                      uint32_t n_leaves, bool active, V3 o, V3 d, const double t_stop,
+                                      double* __restrict__ evD, uint32_t* __restrict__ evM,
+                                      uint16_t* __restrict__ lens, Diag& dg) {
   Hit h = {false, 0.0, 0u, false};
   if (n_leaves == 1) {
     // The root is a bare primitive: its raw list is what trace sees, a lone Exit included.
@@ -33,6 +42,9 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
   // for the box tests; a zero component gives +-inf, which the slab arithmetic below handles
   const V3 inv_d = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
   for (;;) {
+#if GMLRT_TOP_EXIT
+    if (!__ballot(active)) break;  // every lane has what it came for
+#endif
     const ProgSmall* __restrict__ rec = (const ProgSmall*)(prog + pc);
     const uint32_t kf = rec->kind;
     const uint32_t kind = kf & 0xFu;
@@ -49,7 +61,11 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
       const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
       const double r2 = B->radius2;
-      const bool miss = !active || __builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2) || (tca < 0.0 && oc2 > r2);
+      const bool miss = !active || __builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2) || (tca < 0.0 && oc2 > r2)
+#if GMLRT_TMAX_CULL
+                        || (found && tca - B->radius > best)
+#endif
+          ;
       DIAG(dg.n_bound++;)
       if (!__ballot(!miss)) {
         DIAG(dg.n_skip++;)
@@ -72,7 +88,11 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
       const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
       // the relative slack covers the rounding of the six products
-      const bool miss = !active || tfar * (1.0 + 1e-9) < tnear;
+      const bool miss = !active || tfar * (1.0 + 1e-9) < tnear
+#if GMLRT_TMAX_CULL
+                        || (found && tnear > best)
+#endif
+          ;
       DIAG(dg.n_bound++;)
       if (!__ballot(!miss)) {
         DIAG(dg.n_skip++;)
@@ -101,6 +121,9 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
         if (entry) {
           if (sliver) redo = true;
           else if (!found || d0 < best) { found = true; best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift); }
+#if GMLRT_TSTOP
+          if (found && best <= t_stop) active = false;
+#endif
         }
       } else {
         uint32_t n = 0;
@@ -153,6 +176,9 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       if (active && n) {
         const double d0 = evD[0];
         if (!found || d0 < best) { found = true; best = d0; best_m = evM[0]; }
+#if GMLRT_TSTOP
+        if (best <= t_stop) active = false;
+#endif
       }
       sp = 0;
       level = 0;
