@@ -12,13 +12,23 @@
 //    needs no lists at all: its non-union children ("frontier children") are
 //    evaluated one after the other and only the nearest first Entry is kept.
 //
+//    The order in which frontier children are visited is free as long as a tie between two
+//    candidates at the same distance still goes to the one that comes first in the blob's
+//    program; leaves are numbered in program order, so the kernel breaks ties by leaf index.
+//    That freedom is used to regroup the frontier children spatially: a binary tree of boxes
+//    over their bounds (median split of the centroids along the longest axis, nearer to the
+//    camera first), emitted in depth-first order with skip offsets.  The blob's own bounds on
+//    union nodes of the frontier are not used (a chain of unions bounds little).
+//
 // 2. Stream layout.  The program is one byte stream of 16-byte-aligned records with
 //    their operands inline (a bound's sphere, a leaf's inverse matrix), so that one
 //    wave-uniform address gives everything a step needs in a single round of scalar
 //    loads instead of word -> index -> record.
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -100,9 +110,25 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
   if (st.size() != 1) throw std::runtime_error("derive_stream_program: malformed program");
 
   Stream S;
-  auto put_bound = [&](int idx, bool frontier) -> size_t {
+  // Expected number of frontier bound tests per ray, for choosing between two arrangements of
+  // the frontier: a bound is tested when the one around it was entered, which a random ray
+  // does with a probability proportional to that one's surface area.
+  double cost = 0.0, ref_area = 0.0;
+  std::vector<double> open_p;
+  auto smaller_area = [](const gmlrt_bound& g) {
+    double a = 4.0 * 3.14159265358979323846 * g.radius * g.radius;
+    const double e[3] = {g.hi[0] - g.lo[0], g.hi[1] - g.lo[1], g.hi[2] - g.lo[2]};
+    if (e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0) return 0.0;
+    const double b = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+    return std::isfinite(b) && b < a ? b : a;
+  };
+  auto put_bound = [&](const gmlrt_bound& g, bool frontier) -> size_t {
+    if (frontier) {
+      cost += open_p.empty() ? 1.0 : open_p.back();
+      const double pr = ref_area > 0.0 ? smaller_area(g) / ref_area : 1.0;
+      open_p.push_back(pr < 1.0 ? pr : 1.0);
+    }
     // whichever of the two volumes a random ray is less likely to meet (smaller surface area)
-    const gmlrt_bound& g = bounds[idx];
     bool box_ok = true;
     for (int i = 0; i < 3; i++) box_ok = box_ok && std::isfinite(g.lo[i]) && std::isfinite(g.hi[i]);
     if (box_ok) {
@@ -124,9 +150,9 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
     std::memset(&r, 0, sizeof(r));
     r.kind = kRecBound | (frontier ? kRecFlag : 0u);
     r.skip_to = 0;  // patched when the subtree is complete
-    for (int i = 0; i < 3; i++) r.center[i] = bounds[idx].center[i];
-    r.radius2 = bounds[idx].radius * bounds[idx].radius;
-    r.radius = bounds[idx].radius;
+    for (int i = 0; i < 3; i++) r.center[i] = g.center[i];
+    r.radius2 = g.radius * g.radius;
+    r.radius = g.radius;
     return S.put(&r, sizeof(r));
   };
   auto put_leaf = [&](uint32_t leaf, bool take) {
@@ -148,26 +174,46 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
     const uint32_t to = (uint32_t)S.bytes.size();
     std::memcpy(S.bytes.data() + at + offsetof(ProgBound, skip_to), &to, 4);
   };
+  auto close_frontier_bound = [&](size_t at) {
+    patch_skip(at);
+    open_p.pop_back();
+  };
 
-  // explicit stack instead of recursion: union chains can be tens of thousands deep
-  struct Item { int node; int stage; size_t bound_at; };
-  std::vector<Item> work;
-  work.push_back({st[0], 0, 0});
-  while (!work.empty()) {
-    Item it = work.back();
-    work.pop_back();
-    if (it.stage == 1) {  // close a frontier bound: it covers everything emitted since it was opened
-      patch_skip(it.bound_at);
-      continue;
+  // ---- the frontier: operands of the union tree under the root, in program order
+  // (explicit stack instead of recursion: union chains can be tens of thousands deep)
+  std::vector<int> items;
+  {
+    std::vector<int> work{st[0]};
+    while (!work.empty()) {
+      const int ni = work.back();
+      work.pop_back();
+      const PNode& n = tree[(size_t)ni];
+      if ((n.word >> 30) == 1 && (n.word & 3u) == GMLRT_UNION) {
+        work.push_back(n.b);  // reversed: the left child comes off the stack first
+        work.push_back(n.a);
+      } else {
+        items.push_back(ni);
+      }
     }
-    const PNode& n = tree[(size_t)it.node];
-    const bool is_union = (n.word >> 30) == 1 && (n.word & 3u) == GMLRT_UNION;
-    if (n.bound >= 0) work.push_back({it.node, 1, put_bound(n.bound, true)});
-    if (is_union) {
-      // pushed in reverse so that the left child is emitted first
-      work.push_back({n.b, 0, 0});
-      work.push_back({n.a, 0, 0});
-    } else if ((n.word >> 30) == 0) {
+  }
+  // reference area for the cost estimate: the box around everything that has a bound
+  {
+    gmlrt_bound all;
+    for (int k = 0; k < 3; k++) { all.lo[k] = INFINITY; all.hi[k] = -INFINITY; all.center[k] = 0.0; }
+    all.radius = INFINITY;
+    for (int ni : items) {
+      if (tree[(size_t)ni].bound < 0) continue;
+      const gmlrt_bound& b = bounds[tree[(size_t)ni].bound];
+      for (int k = 0; k < 3; k++) { all.lo[k] = std::min(all.lo[k], b.lo[k]); all.hi[k] = std::max(all.hi[k], b.hi[k]); }
+    }
+    ref_area = smaller_area(all);
+    if (!std::isfinite(ref_area)) ref_area = 0.0;
+  }
+  auto emit_item = [&](int ni) {
+    const PNode& n = tree[(size_t)ni];
+    size_t bound_at = 0;
+    if (n.bound >= 0) bound_at = put_bound(bounds[n.bound], true);
+    if ((n.word >> 30) == 0) {
       put_leaf(n.word & 0x3FFFFFFFu, true);  // frontier leaf: candidate for the nearest Entry, no list
     } else {
       // frontier child with an operator at its top: its words in order, then take the first element
@@ -175,7 +221,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
       std::vector<std::pair<uint32_t, size_t>> inner;  // (word index one past the subtree, record offset)
       for (uint32_t i = begin; i <= n.last; i++) {
         const uint32_t w = nodes[i];
-        if ((w >> 30) == 2) inner.emplace_back(i + 1 + (w & 0x7FFFu), put_bound((int)((w >> 15) & 0x7FFFu), false));
+        if ((w >> 30) == 2) inner.emplace_back(i + 1 + (w & 0x7FFFu), put_bound(bounds[(w >> 15) & 0x7FFFu], false));
         else if ((w >> 30) == 0) put_leaf(w & 0x3FFFFFFFu, false);
         else put_small(kRecOp, w & 0xFu);
         while (!inner.empty() && inner.back().first == i + 1) {
@@ -185,7 +231,139 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
       }
       put_small(kRecTake, 0);
     }
+    if (n.bound >= 0) close_frontier_bound(bound_at);
+  };
+
+  // Arrangement 1: the union tree as the blob has it, with the bounds the blob put on its nodes
+  // (a scene built recursively is a good hierarchy already).
+  auto emit_as_given = [&]() {
+    struct Item { int node; int stage; size_t bound_at; };
+    std::vector<Item> work;
+    work.push_back({st[0], 0, 0});
+    while (!work.empty()) {
+      Item it = work.back();
+      work.pop_back();
+      if (it.stage == 1) {  // close a union's bound: it covers everything emitted since it was opened
+        close_frontier_bound(it.bound_at);
+        continue;
+      }
+      const PNode& n = tree[(size_t)it.node];
+      if ((n.word >> 30) == 1 && (n.word & 3u) == GMLRT_UNION) {
+        if (n.bound >= 0) work.push_back({it.node, 1, put_bound(bounds[n.bound], true)});
+        work.push_back({n.b, 0, 0});  // reversed: the left child is emitted first
+        work.push_back({n.a, 0, 0});
+      } else {
+        emit_item(it.node);
+      }
+    }
+  };
+
+  // Arrangement 2: the frontier children regrouped spatially (objects added to the scene one by
+  // one make a chain of unions, which bounds little).  Children without a finite bound
+  // (half-spaces) are visited by every ray, and so is, in effect, a child that spans most of the
+  // scene (a floor slab): both stay outside the tree and come first, so that a hit on them can
+  // already cull what lies behind it.
+  auto emit_regrouped = [&]() {
+  std::vector<int> grouped;
+  {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto box_area = [](const double* l, const double* h) {
+      const double e[3] = {h[0] - l[0], h[1] - l[1], h[2] - l[2]};
+      if (e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0) return 0.0;
+      return 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+    };
+    for (int ni : items) {
+      if (tree[(size_t)ni].bound < 0) continue;
+      const gmlrt_bound& b = bounds[tree[(size_t)ni].bound];
+      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+    const double all_area = box_area(lo, hi);
+    for (int ni : items) {
+      const int bi = tree[(size_t)ni].bound;
+      if (bi < 0 || !(box_area(bounds[bi].lo, bounds[bi].hi) <= 0.25 * all_area)) emit_item(ni);
+      else grouped.push_back(ni);
+    }
   }
+  struct Range { size_t lo, hi; int stage; size_t bound_at; };
+  auto centroid = [&](int ni, int axis) {
+    const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
+    return 0.5 * (g.lo[axis] + g.hi[axis]);
+  };
+  const double cam[3] = {0.0, 0.0, -1.0};  // raytracer.rs:138
+  std::vector<Range> ranges;
+  ranges.push_back({0, grouped.size(), 0, 0});
+  while (!ranges.empty()) {
+    Range r = ranges.back();
+    ranges.pop_back();
+    if (r.stage == 1) { close_frontier_bound(r.bound_at); continue; }
+    const size_t n = r.hi - r.lo;
+    if (n == 0) continue;
+    if (n == 1) { emit_item(grouped[r.lo]); continue; }
+    // box of the group and of its centroids
+    gmlrt_bound g;
+    double clo[3], chi[3];
+    for (int k = 0; k < 3; k++) { g.lo[k] = clo[k] = INFINITY; g.hi[k] = chi[k] = -INFINITY; }
+    for (size_t i = r.lo; i < r.hi; i++) {
+      const gmlrt_bound& b = bounds[tree[(size_t)grouped[i]].bound];
+      for (int k = 0; k < 3; k++) {
+        g.lo[k] = std::min(g.lo[k], b.lo[k]);
+        g.hi[k] = std::max(g.hi[k], b.hi[k]);
+        const double c = centroid(grouped[i], k);
+        clo[k] = std::min(clo[k], c);
+        chi[k] = std::max(chi[k], c);
+      }
+    }
+    bool finite = true;
+    double h2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+      finite = finite && std::isfinite(g.lo[k]) && std::isfinite(g.hi[k]);
+      g.center[k] = 0.5 * (g.lo[k] + g.hi[k]);
+      const double h = 0.5 * (g.hi[k] - g.lo[k]);
+      h2 += h * h;
+    }
+    g.radius = std::sqrt(h2) * (1.0 + 1e-9) + 1e-12;  // the box's circumscribed sphere
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    const size_t mid = r.lo + n / 2;
+    std::nth_element(grouped.begin() + (long)r.lo, grouped.begin() + (long)mid, grouped.begin() + (long)r.hi,
+                     [&](int x, int y) {
+                       const double cx = centroid(x, axis), cy = centroid(y, axis);
+                       return cx < cy || (cx == cy && x < y);
+                     });
+    // the half whose centroids lie nearer to the camera goes first
+    double dl = 0.0, dr = 0.0;
+    for (int k = 0; k < 3; k++) {
+      double ml = 0.0, mr = 0.0;
+      for (size_t i = r.lo; i < mid; i++) ml += centroid(grouped[i], k);
+      for (size_t i = mid; i < r.hi; i++) mr += centroid(grouped[i], k);
+      ml = ml / (double)(mid - r.lo) - cam[k];
+      mr = mr / (double)(r.hi - mid) - cam[k];
+      dl += ml * ml;
+      dr += mr * mr;
+    }
+    if (dr < dl) std::rotate(grouped.begin() + (long)r.lo, grouped.begin() + (long)mid, grouped.begin() + (long)r.hi);
+    const size_t cut = dr < dl ? r.lo + (r.hi - mid) : mid;
+    // the root group of a scene that is bounded as a whole still gets its box: rays that miss everything leave at once
+    if (finite && std::isfinite(g.radius)) ranges.push_back({0, 0, 1, put_bound(g, true)});
+    ranges.push_back({cut, r.hi, 0, 0});  // popped second
+    ranges.push_back({r.lo, cut, 0, 0});  // popped first
+  }
+  };
+
+  // emit both, keep the one with the smaller expected number of bound tests
+  emit_as_given();
+  const double cost_given = cost;
+  std::vector<uint8_t> given;
+  given.swap(S.bytes);
+  cost = 0.0;
+  open_p.clear();
+  emit_regrouped();
+  bool regroup = cost < cost_given;
+  if (const char* e = std::getenv("GMLRT_REGROUP")) regroup = *e == '1';  // tuning runs
+  if (std::getenv("GMLRT_VERBOSE"))
+    std::fprintf(stderr, "[gmlrt] frontier of %zu children: expected bound tests per ray %.2f as given, %.2f regrouped -> %s\n",
+                 items.size(), cost_given, cost, regroup ? "regrouped" : "as given");
+  if (!regroup) S.bytes.swap(given);
   put_small(kRecEnd, 0);
   if (S.bytes.size() >= 0xFFFFFFF0ull) throw std::runtime_error("derived program too large");
   return S.bytes;

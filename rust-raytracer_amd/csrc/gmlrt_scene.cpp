@@ -782,13 +782,18 @@ struct Flattener : gml::TreeVisitor {
   // surface-area ratios; the environment overrides exist for tuning runs
   static double op_ratio() { static const double v = ratio_from_env("GMLRT_BOUND_OP_RATIO", 0.8); return v; }
   static double leaf_ratio() { static const double v = ratio_from_env("GMLRT_BOUND_LEAF_RATIO", 0.8); return v; }
-  void emit(int ni, double enclosing_area) {
+  // `frontier`: the node hangs from the root through unions only.  The first non-union node
+  // on such a path (an operand of the root's union tree) always gets its bound when it has a
+  // finite one: a consumer that regroups those operands spatially needs each one's volume.
+  void emit(int ni, double enclosing_area, bool frontier) {
     const FNode& n = tree[(size_t)ni];
     const bool is_leaf = n.leaf >= 0;
+    const bool is_union = !is_leaf && n.rule == gml::Rule::Union;
     const uint64_t worst_words = 2ull * (2ull * n.n_leaves - 1ull);
     const double area = n.bnd.area();
     bool want = n.bnd.finite && bounds.size() < GMLRT_BOUND_MAX && worst_words <= GMLRT_BOUND_MAX;
-    if (want && std::isfinite(enclosing_area)) want = area <= (is_leaf ? leaf_ratio() : op_ratio()) * enclosing_area;
+    if (want && std::isfinite(enclosing_area) && !(frontier && !is_union))
+      want = area <= (is_leaf ? leaf_ratio() : op_ratio()) * enclosing_area;
     size_t at = 0;
     if (want) {
       at = nodes.size();
@@ -807,8 +812,8 @@ struct Flattener : gml::TreeVisitor {
       max_events = std::max(max_events, sp);
       max_stack = std::max(max_stack, ostack.size());
     } else {
-      emit(n.a, inner_r);
-      emit(n.b, inner_r);
+      emit(n.a, inner_r, frontier && is_union);
+      emit(n.b, inner_r, frontier && is_union);
       auto b = ostack.back(); ostack.pop_back();
       auto a = ostack.back(); ostack.pop_back();
       nodes.push_back(GMLRT_NODE_OP((uint32_t)n.rule, a.first, b.first));
@@ -833,7 +838,7 @@ void append(std::vector<uint8_t>& blob, uint64_t* off, const std::vector<T>& v) 
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc) {
   Flattener f;
   gml::walk_postfix(rc.scene, f);
-  f.emit(f.tstack.back(), std::numeric_limits<double>::infinity());
+  f.emit(f.tstack.back(), std::numeric_limits<double>::infinity(), true);
   std::vector<gmlrt_light> lights;
   for (auto& l : rc.lights) {
     gmlrt_light g;

@@ -120,7 +120,9 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
         // frontier leaf: no list, just a candidate for the nearest first Entry
         if (entry) {
           if (sliver) redo = true;
-          else if (!found || d0 < best) { found = true; best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift); }
+          else if (!found || d0 < best || (d0 == best && leaf < (best_m & kLeafMask))) {
+            found = true; best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift);
+          }
 #if GMLRT_TSTOP
           if (found && best <= t_stop) active = false;
 #endif
@@ -175,7 +177,8 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       DIAG(dg.n_take++;)
       if (active && n) {
         const double d0 = evD[0];
-        if (!found || d0 < best) { found = true; best = d0; best_m = evM[0]; }
+        const uint32_t m0 = evM[0];
+        if (!found || d0 < best || (d0 == best && (m0 & kLeafMask) < (best_m & kLeafMask))) { found = true; best = d0; best_m = m0; }
 #if GMLRT_TSTOP
         if (best <= t_stop) active = false;
 #endif
