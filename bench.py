@@ -35,6 +35,19 @@ F_PRIM = {0: 61, 1: 60, 2: 70, 3: 77, 4: 47}
 F_SHADE = 150
 PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X vector FP64 (the path computes in f64)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32, the figure the project metric names
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+
+
+def measured_counters(workload):
+    """Memory-side bytes per launch and VALU busy fraction of the headline workload, as collected with
+    rocprofv3 --pmc (tools/profile_round.sh) and committed under profiles/; None for any other workload."""
+    if workload != "chess.gml 3840x2160 depth 5":
+        return None, None
+    try:
+        d = json.load(open(PMC_SUMMARY))["derived"]
+        return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], d["valu_busy_fraction"]
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def scene_flops_per_ray(blob):
@@ -151,12 +164,15 @@ def main():
         my_kernel_ms = kernel_ms / args.steps
         flops = my_rays * flops_per_ray + my_hits * F_SHADE
         achieved = flops / (my_kernel_ms * 1e-3) / 1e12
+        workload = "%s %dx%d depth %d" % (os.path.basename(args.scene), w, h, call.params.depth)
+        headline = workload == "chess.gml 3840x2160 depth 5"
+        traffic, valu_busy = measured_counters(workload) if world == 1 else (None, None)
         line = {
-            "metric": "Mrays/s (primary+shadow+reflect), chess.gml 4K depth 5",
+            "metric": "Mrays/s (primary+shadow+reflect), " + ("chess.gml 4K depth 5" if headline else workload),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s %dx%d depth %d" % (os.path.basename(args.scene), w, h, call.params.depth),
+            "config": {"workload": workload,
                        "leaves": n_leaves, "flops_per_ray": flops_per_ray,
                        "rays_per_frame": int(rays_per_step), "parallelism": "row-tiles x%d (tile %d rows)" % (world, TILE_ROWS)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP64_VALU_TFLOPS,
@@ -164,7 +180,7 @@ def main():
                          "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 5),
                          "kernel": "render_kernel", "kernel_ms": round(my_kernel_ms, 4),
                          "kernel_Mrays_per_s": round(my_rays / (my_kernel_ms * 1e-3) / 1e6, 3),
-                         "traffic": None},
+                         "traffic": traffic, "valu_busy_measured": valu_busy},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
