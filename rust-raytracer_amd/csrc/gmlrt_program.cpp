@@ -365,6 +365,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
                  items.size(), cost_given, cost, regroup ? "regrouped" : "as given");
   if (!regroup) S.bytes.swap(given);
   put_small(kRecEnd, 0);
+  S.bytes.resize(S.bytes.size() + 64, 0);  // the traversal reads 64 bytes at every record, the last one included
   if (S.bytes.size() >= 0xFFFFFFF0ull) throw std::runtime_error("derived program too large");
   return S.bytes;
 }

@@ -45,25 +45,30 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
 #if GMLRT_TOP_EXIT
     if (!__ballot(active)) break;  // every lane has what it came for
 #endif
-    const ProgSmall* __restrict__ rec = (const ProgSmall*)(prog + pc);
-    const uint32_t kf = rec->kind;
+    // The first 64 bytes of the record, whatever its kind, in one scalar load: fetching the
+    // kind first and the operands after the branch on it would be two dependent round trips
+    // per record.  (The program is padded so that this never reads past its buffer.)
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    const u32x16 R = *(const u32x16*)(const void*)(prog + pc);
+#define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
+    const uint32_t kf = R[0];
     const uint32_t kind = kf & 0xFu;
     if (kind == kRecBound) {
       // Bounding sphere in front of a subtree: if no lane's ray comes near it, every
       // list below is empty.  Under the union frontier that means "nothing to take";
       // inside a frontier child the subtree's (empty) list is pushed.
-      const ProgBound* __restrict__ B = (const ProgBound*)(prog + pc);
+      // ProgBound: skip_to, center[3], radius2, radius
       // The test only has to be conservative, not reproducible, so it uses fused
       // multiply-adds and |perp|^2 = |oc|^2 - tca^2 (d has unit length); the slack added to
       // r^2 covers the cancellation in that difference.  Any NaN compares false and keeps
       // the subtree.
-      const double ocx = B->center[0] - o.x, ocy = B->center[1] - o.y, ocz = B->center[2] - o.z;
+      const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
       const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
       const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
-      const double r2 = B->radius2;
+      const double r2 = REC_F64(3);
       const bool miss = !active || __builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2) || (tca < 0.0 && oc2 > r2)
 #if GMLRT_TMAX_CULL
-                        || (found && tca - B->radius > best)
+                        || (found && tca - REC_F64(4) > best)
 #endif
           ;
       DIAG(dg.n_bound++;)
@@ -73,7 +78,7 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
           lens[level * kBlock + tid] = 0;
           level++;
         }
-        pc = B->skip_to;
+        pc = R[1];
       } else {
         pc += (uint32_t)sizeof(ProgBound);
       }
@@ -81,10 +86,10 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       // The same for the subtree's axis-aligned box: slab test.  fmin/fmax return the
       // other operand when one is NaN (0 * inf: the ray runs inside a face plane), which
       // leaves that slab out; a NaN direction keeps the subtree.
-      const ProgBox* __restrict__ B = (const ProgBox*)(prog + pc);
-      const double x1 = (B->lo[0] - o.x) * inv_d.x, x2 = (B->hi[0] - o.x) * inv_d.x;
-      const double y1 = (B->lo[1] - o.y) * inv_d.y, y2 = (B->hi[1] - o.y) * inv_d.y;
-      const double z1 = (B->lo[2] - o.z) * inv_d.z, z2 = (B->hi[2] - o.z) * inv_d.z;
+      // ProgBox: skip_to, lo[3], hi[3]
+      const double x1 = (REC_F64(0) - o.x) * inv_d.x, x2 = (REC_F64(3) - o.x) * inv_d.x;
+      const double y1 = (REC_F64(1) - o.y) * inv_d.y, y2 = (REC_F64(4) - o.y) * inv_d.y;
+      const double z1 = (REC_F64(2) - o.z) * inv_d.z, z2 = (REC_F64(5) - o.z) * inv_d.z;
       const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
       const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
       // the relative slack covers the rounding of the six products
@@ -100,16 +105,19 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
           lens[level * kBlock + tid] = 0;
           level++;
         }
-        pc = B->skip_to;
+        pc = R[1];
       } else {
         pc += (uint32_t)sizeof(ProgBox);
       }
     } else if (kind == kRecLeaf) {
+      // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
       const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
+      const double im[12] = {REC_F64(0), REC_F64(1), REC_F64(2), REC_F64(3), REC_F64(4), REC_F64(5), REC_F64(6),
+                             L->inv_m[7], L->inv_m[8], L->inv_m[9], L->inv_m[10], L->inv_m[11]};
       double scale; V3 rd, rp;
-      to_object(L->inv_m, o, d, scale, rd, rp);
+      to_object(im, o, d, scale, rd, rp);
       PrimHit ph = isect_prim((kf >> 16) & 7u, rp, rd);
-      const uint32_t leaf = L->leaf;
+      const uint32_t leaf = R[1];
       DIAG(dg.n_leaf++;)
       // a list that starts with Exit never raises its operand's counter above zero
       // (primitives.rs:254-293 start both counters at 0): same as no list at all
@@ -145,7 +153,7 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       }
       pc += (uint32_t)sizeof(ProgLeaf);
     } else if (kind == kRecOp) {
-      const uint32_t rule = rec->arg & 3u;
+      const uint32_t rule = R[1] & 3u;
       const uint32_t lenB = lens[(level - 1) * kBlock + tid], lenA = lens[(level - 2) * kBlock + tid];
       const uint32_t lb = lenB & 0x7FFFu, la = lenA & 0x7FFFu;
       const bool slvA = lenA >> 15, slvB = lenB >> 15;
@@ -190,6 +198,7 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
       break;  // kRecEnd
     }
   }
+#undef REC_F64
   h.any = found;
   h.dist = best;
   h.meta = best_m;
