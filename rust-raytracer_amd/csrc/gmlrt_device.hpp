@@ -69,6 +69,15 @@ struct DeviceScene {
   size_t ev_slots_alloc = 0;    // event slots per lane currently allocated
   size_t ctx_fields_alloc = 0;  // f64 fields per lane currently allocated
   size_t lanes_alloc = 0;
+  // hand-out order of the pixel tiles, learnt from the first launch with a given geometry
+  void* d_tile_cost = nullptr;  // u32 per tile, written by every launch
+  void* d_tile_order = nullptr; // u32 per tile: tiles sorted by decreasing cost
+  size_t tiles_alloc = 0;
+  bool order_valid = false;     // d_tile_order holds an order for order_key
+  int order_state = 0;          // 0: nothing learnt, 1: order built, on trial in the next launch, 2: decided
+  bool order_use = false;       // the trial launch was faster than the one in image order
+  float order_base_ms = 0.f;    // kernel time of the launch in image order
+  gmlrt_params order_key{};     // the launch parameters the order belongs to (ambient zeroed)
   void* ev_start = nullptr;     // hipEvent_t pair used to time the kernel
   void* ev_stop = nullptr;
 };

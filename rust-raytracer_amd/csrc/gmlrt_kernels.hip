@@ -21,7 +21,9 @@
 // bit; only libm-class functions (pow, atan2, asin ...) may differ in the last ulp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -41,6 +43,7 @@ constexpr uint32_t kCurExit = 1u << 24;   // current type after operator switche
 constexpr uint32_t kHitAny = 1u << 31;    // set in the meta word handed to after_traversal: the ray hit something
 constexpr int kCtxFixed = 24;             // f64 fields of the shading context before the bounce stack
 constexpr int kCtxPerLevel = 7;
+[[maybe_unused]] constexpr int kDiagWaveSlots = 12;  // diagnostic build: counters per wave
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
 
@@ -75,6 +78,8 @@ struct KArgs {
   uint32_t n_vm_fast;    // surface-bytecode registers kept in LDS (the rest live in the context record)
   uint32_t vm_lds_off;   // byte offset of that LDS region (after the operand-stack lengths)
   uint32_t lds_ctx;      // 1: the region also holds the hot fields of the shading context
+  const uint32_t* tile_order;  // tile to render for the i-th hand-out; null: i itself
+  uint32_t* tile_cost;         // per tile: how long its wave spent on it (wall-clock ticks); null: not wanted
   unsigned int* next_slot;
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
@@ -398,8 +403,15 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   bool more = true;        // the global counter still has tiles
   uint32_t tile_base = 0;  // next slot of the wave's tile
   uint32_t tile_left = 0;  // slots of it not handed out yet
+  // Tiles differ a lot in cost (sky: one traversal; a piece between mirrors: a dozen heavy ones) and
+  // a wave follows its tile through every bounce, so the launch ends when the last expensive tile
+  // does.  Each wave therefore notes how long its tiles took; the host sorts that into the hand-out
+  // order (dearest first) of later launches with the same geometry.
+  uint32_t cur_tile = 0xFFFFFFFFu;
+  unsigned long long tile_t0 = 0;
   Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  DIAG(unsigned long long t0 = __builtin_readcyclecounter();)
+  DIAG(unsigned long long t0 = __builtin_readcyclecounter(); const unsigned long long w_start = wall_clock64();
+       unsigned long long w_tiles = 0;)
 
   for (;;) {
     // ---- hand new pixels to idle lanes
@@ -409,9 +421,16 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(A.next_slot, 64u);
         t = (uint32_t)__shfl((int)t, 0);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        const unsigned long long now = A.tile_cost ? wall_clock64() : 0ull;
+        if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(now - tile_t0);
+        cur_tile = 0xFFFFFFFFu;
         if (t >= A.n_slots) { more = false; break; }
         tile_base = t;
         tile_left = 64u;
+        cur_tile = A.tile_order ? A.tile_order[t >> 6] : (t >> 6);
+        tile_t0 = now;
+        DIAG(w_tiles++;)
       }
       const uint32_t want = (uint32_t)__popcll(idle);
       const uint32_t take = want < tile_left ? want : tile_left;
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       if (st_kind(S.st) == kIdle && rank < take) {
         // slot -> 8x8 tile -> pixel of this partition's packed rows
         const uint32_t slot = tile_base + rank;
-        const uint32_t tile = slot >> 6, in = slot & 63u;
+        const uint32_t tile = cur_tile, in = slot & 63u;
         const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
         const uint32_t yl = (tile / A.tiles_x) * 8u + (in >> 3);
         if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
@@ -469,6 +488,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(t0 = __builtin_readcyclecounter(); dg.t_after += t0 - t2;)
   }
 
+  if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(wall_clock64() - tile_t0);
+
   // ---- ray counters: one atomic per wave and kind
   for (int off = 32; off > 0; off >>= 1) {
     n_primary += (uint32_t)__shfl_down((int)n_primary, off);
@@ -481,6 +502,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     atomicAdd(&A.ray_counts[1], (unsigned long long)n_shadow);
     atomicAdd(&A.ray_counts[2], (unsigned long long)n_reflect);
     atomicAdd(&A.ray_counts[3], (unsigned long long)n_hits);
+    DIAG(shade_args->diag_waves[wave * kDiagWaveSlots + 8] = w_start; shade_args->diag_waves[wave * kDiagWaveSlots + 9] = wall_clock64();
+         shade_args->diag_waves[wave * kDiagWaveSlots + 10] = w_tiles;)
     DIAG(atomicAdd(&A.diag[0], dg.t_refill); atomicAdd(&A.diag[1], dg.t_trav); atomicAdd(&A.diag[2], dg.t_after);
          atomicAdd(&A.diag[3], dg.n_trav); atomicAdd(&A.diag[4], dg.n_bound); atomicAdd(&A.diag[5], dg.n_skip);
          atomicAdd(&A.diag[6], dg.n_leaf); atomicAdd(&A.diag[7], dg.n_merge); atomicAdd(&A.diag[8], dg.n_take);
@@ -568,6 +591,8 @@ void dev_scene_destroy(DeviceScene* s) {
   if (hipSetDevice(s->device) != hipSuccess) return;
   (void)hipFree(s->d_blob);
   (void)hipFree(s->d_prog);
+  (void)hipFree(s->d_tile_cost);
+  (void)hipFree(s->d_tile_order);
   (void)hipFree(s->d_surf);
   (void)hipFree(s->d_leaf_surf);
   (void)hipFree(s->d_ev_dist);
@@ -699,6 +724,26 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.ev_cap = (uint32_t)s->ev_slots_alloc;
   A.ctx = (double*)s->d_ctx;
   A.ctx_fields = (uint32_t)s->ctx_fields_alloc;
+  // ---- tile order: costs of an earlier launch with the same geometry, dearest first
+  const size_t n_tiles = (size_t)(n_slots / 64);
+  if (n_tiles > s->tiles_alloc) {
+    (void)hipFree(s->d_tile_cost);
+    (void)hipFree(s->d_tile_order);
+    s->d_tile_cost = s->d_tile_order = nullptr;
+    HIP_TRY(hipMalloc(&s->d_tile_cost, n_tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_tile_order, n_tiles * sizeof(uint32_t)));
+    s->tiles_alloc = n_tiles;
+    s->order_valid = false;
+  }
+  gmlrt_params key = p;
+  key.amb[0] = key.amb[1] = key.amb[2] = 0.0;  // the ambient colour moves no ray
+  key.tile_rows = A.tile_rows; key.part = A.part; key.nparts = A.nparts; key.reserved = 0;
+  if (s->order_valid && std::memcmp(&key, &s->order_key, sizeof(key)) != 0) s->order_valid = false;
+  if (!s->order_valid) s->order_state = 0;
+  static const bool no_order = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
+  const bool ordered = s->order_valid && !no_order && (s->order_state == 1 || (s->order_state == 2 && s->order_use));
+  A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
+  A.tile_cost = s->order_state == 0 && !no_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
   A.next_slot = (unsigned int*)s->d_counters;
   A.ray_counts = (unsigned long long*)((uint8_t*)s->d_counters + 8);
   A.diag = (unsigned long long*)((uint8_t*)s->d_counters + 64);
@@ -722,8 +767,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.surf_prog = (const SurfInstr*)s->d_surf;
 #ifdef GMLRT_DIAG
   unsigned long long* d_diag_waves = nullptr;
-  HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * 8 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * 8 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long), stream));
   SA.diag_waves = d_diag_waves;
 #endif
   HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
@@ -737,20 +782,66 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
+  if (s->order_state == 1 && ordered) {
+    // the trial: keep the order only if it paid (it trades cache locality between neighbouring waves
+    // for a shorter tail; scenes with evenly priced tiles lose)
+    s->order_use = ms < 0.98f * s->order_base_ms;
+    s->order_state = 2;
+  } else if (s->order_state == 0 && !no_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
+    // first launch with this geometry: turn its per-tile costs into the order of the next ones
+    // (worth it only when a wave renders several tiles)
+    std::vector<uint32_t> cost(n_tiles), order(n_tiles);
+    HIP_TRY(hipMemcpy(cost.data(), s->d_tile_cost, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // Sorted by cost class only (a few classes up to the dearest tile), image order within a class:
+    // neighbouring tiles walk the same parts of the scene program, and waves that run side by side
+    // should keep sharing them in cache.
+    static const uint32_t n_classes = [] { const char* e = std::getenv("GMLRT_TILE_CLASSES"); return e ? (uint32_t)std::atoi(e) : 16u; }();
+    uint32_t top = 1;
+    for (size_t i = 0; i < n_tiles; i++) top = std::max(top, cost[i]);
+    for (size_t i = 0; i < n_tiles; i++) {
+      order[i] = (uint32_t)i;
+      cost[i] = (uint32_t)((uint64_t)cost[i] * n_classes / ((uint64_t)top + 1));
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    s->order_key = key;
+    s->order_valid = true;
+    s->order_state = 1;
+    s->order_base_ms = ms;
+  }
 #ifdef GMLRT_DIAG
   {
     unsigned long long dgv[16];
     HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + 64, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     {
-      std::vector<unsigned long long> per_wave(lanes / kWave * 8);
+      std::vector<unsigned long long> per_wave(lanes / kWave * kDiagWaveSlots);
       HIP_TRY(hipMemcpy(per_wave.data(), d_diag_waves, per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       (void)hipFree(d_diag_waves);
       unsigned long long vm_runs = 0, vm_lanes = 0;
       for (int q = 0; q < 6; q++) dgv[10 + q] = 0;
       for (size_t wv = 0; wv < lanes / kWave; wv++) {
-        for (int q = 0; q < 6; q++) dgv[10 + q] += per_wave[wv * 8 + q];
-        vm_runs += per_wave[wv * 8 + 6];
-        vm_lanes += per_wave[wv * 8 + 7];
+        for (int q = 0; q < 6; q++) dgv[10 + q] += per_wave[wv * kDiagWaveSlots + q];
+        vm_runs += per_wave[wv * kDiagWaveSlots + 6];
+        vm_lanes += per_wave[wv * kDiagWaveSlots + 7];
+      }
+      {
+        // when did each wave finish, relative to the first start (100 MHz wall clock)
+        unsigned long long first = ~0ull, last = 0, sum = 0, tiles_max = 0, tiles_sum = 0;
+        const size_t nw = lanes / kWave;
+        std::vector<unsigned long long> ends;
+        for (size_t wv = 0; wv < nw; wv++) first = std::min(first, per_wave[wv * kDiagWaveSlots + 8]);
+        for (size_t wv = 0; wv < nw; wv++) {
+          const unsigned long long e = per_wave[wv * kDiagWaveSlots + 9] - first;
+          ends.push_back(e);
+          last = std::max(last, e);
+          sum += e;
+          tiles_max = std::max(tiles_max, per_wave[wv * kDiagWaveSlots + 10]);
+          tiles_sum += per_wave[wv * kDiagWaveSlots + 10];
+        }
+        std::sort(ends.begin(), ends.end());
+        std::fprintf(stderr, "[gmlrt diag] wave end times (us): p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f mean %.0f; tiles per wave mean %.1f max %llu\n",
+                     ends[nw / 10] / 100.0, ends[nw / 2] / 100.0, ends[nw * 9 / 10] / 100.0, ends[nw * 99 / 100] / 100.0, last / 100.0,
+                     (double)sum / (double)nw / 100.0, (double)tiles_sum / (double)nw, tiles_max);
       }
       std::fprintf(stderr, "[gmlrt diag] surface program runs %llu (%.2f per traversal), lanes wanting one %.1f per traversal\n",
                    vm_runs, (double)vm_runs / ((double)dgv[3] > 0 ? (double)dgv[3] : 1.0),

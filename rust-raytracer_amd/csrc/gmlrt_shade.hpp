@@ -243,7 +243,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
        if (lid == (uint32_t)__builtin_amdgcn_readfirstlane((int)lid)) {
          // the wave's own row of the per-wave table: plain adds, no contention
          unsigned long long* dq = global_space(wave_uniform(SA->diag_waves)) +
-                                  ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * 8;
+                                  ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * kDiagWaveSlots;
          dq[0] += tq1 - tq0; dq[1] += tq2 - tq1; dq[2] += tq3 - tq2; dq[3] += tq4 - tq3; dq[4] += tq5 - tq4;
          dq[5] += tq6 - tq5; dq[6] += tq_runs; dq[7] += tq_lanes;
        })

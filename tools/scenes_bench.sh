@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 : > gpurun_out/scenes_bench.txt
 for s in spheres chess fractal cone-fractal spotlight house large; do
-  timeout -k 10 200 python bench.py --scene scenes/$s.gml --steps 3 --warmup 1 --no-cpu-baseline ${DEPTH:+--depth $DEPTH} > gpurun_out/scene_one.json 2> gpurun_out/scene_one.err || { echo "$s FAILED" >> gpurun_out/scenes_bench.txt; tail -3 gpurun_out/scene_one.err >> gpurun_out/scenes_bench.txt; continue; }
+  timeout -k 10 200 python bench.py --scene scenes/$s.gml --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${DEPTH:+--depth $DEPTH} > gpurun_out/scene_one.json 2> gpurun_out/scene_one.err || { echo "$s FAILED" >> gpurun_out/scenes_bench.txt; tail -3 gpurun_out/scene_one.err >> gpurun_out/scenes_bench.txt; continue; }
   python - "$s" <<'PY' >> gpurun_out/scenes_bench.txt
 import json,sys
 d=json.load(open("gpurun_out/scene_one.json"))
