@@ -153,3 +153,22 @@ def test_render_without_init_or_gpu_fails_loudly(gmlrt):
                           ctypes.byref(st)) == -9
     h = ctypes.c_void_p()
     assert L.gmlrt_scene_create(c.blob, len(c.blob), 0, ctypes.byref(h)) == -3
+
+
+# The reference's other scene files: (renders, leaves of the first render).  The front-end must evaluate
+# them and every surface function in them must compile; the files meant to fail must fail with an error
+# code, not a crash (features.gml and illegal.gml index an empty array, syntax*.gml are malformed).
+@pytest.mark.parametrize("name,renders,leaves", [
+    ("checked-cube", 1, 1), ("cone", 4, 1), ("cube", 6, 1), ("cylinder", 4, 1), ("dice", 1, 46), ("ellipsoid", 2, 2),
+    ("fov", 4, 3), ("golf", 1, 8), ("holes", 2, 1), ("intercyl", 1, 3), ("intersect", 1, 2), ("pipe", 1, 8),
+    ("rotate", 1, 3), ("single-sphere", 1, 1), ("snowgoon", 1, 34), ("tower", 1, 19), ("two-spheres", 1, 3)])
+def test_other_reference_scenes_flatten(gmlrt, name, renders, leaves):
+    prog = gmlrt.Program(path=os.path.join(SCENES, name + ".gml"))
+    assert len(prog.calls) == renders
+    assert struct.unpack_from("<I", prog.calls[0].blob, 16)[0] == leaves
+
+
+@pytest.mark.parametrize("name", ["features", "illegal", "syntax1", "syntax2", "syntax3"])
+def test_failing_programs_fail_cleanly(gmlrt, name):
+    with pytest.raises(gmlrt.GmlrtError):
+        gmlrt.Program(path=os.path.join(SCENES, name + ".gml"))

@@ -184,3 +184,30 @@ def test_bound_volumes_do_not_change_results(gmlrt, oracle, label, scene, size):
     assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
     assert np.abs(f64 - ref64).max() <= 1e-9
     assert st.rays_shadow > 0 and st.rays_reflect > 0
+
+
+# The reference's other scene files (its gml/ directory): every `render` each program executes, at the
+# size and depth the file names.  They exercise what the seven configuration scenes do not: array `get`
+# inside surface functions (checked-cube, cube), closures as values (holes), clampf/frac (golf), several
+# render calls per program with different transforms (cone, cube, cylinder, fov), every CSG rule nested (dice,
+# tower, pipe, intercyl).
+OTHER_SCENES = ["checked-cube", "cone", "cube", "cylinder", "dice", "ellipsoid", "fov", "golf", "holes", "intercyl",
+                "intersect", "pipe", "rotate", "single-sphere", "snowgoon", "tower", "two-spheres"]
+
+
+@pytest.mark.parametrize("name", OTHER_SCENES)
+def test_other_reference_scenes_match_oracle(gmlrt, oracle, name):
+    path = os.path.join(SCENES, name + ".gml")
+    prog = gmlrt.Program(path=path)
+    op = oracle.OracleProgram(path=path)
+    assert len(prog.calls) == op.num_renders and len(prog.calls) >= 1
+    for i, call in enumerate(prog.calls):
+        img, f64, st = gmlrt.render(call, want_f64=True)
+        ref, ref64, cnt = op.render(i, threads=8, want_f64=True)
+        frac1, maxd, ndiff = image_diff(img, ref)
+        print(name, i, "differing=%d max=%d" % (ndiff, maxd), st.as_dict())
+        assert frac1 >= 0.999 and maxd <= 8
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+        both = np.isfinite(f64) & np.isfinite(ref64)
+        assert (np.isfinite(f64) == np.isfinite(ref64)).all()
+        assert np.abs(f64[both] - ref64[both]).max() <= 1e-9
