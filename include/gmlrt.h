@@ -33,7 +33,8 @@ enum gmlrt_status {
   GMLRT_ERR_UNSUPPORTED_SURFACE = -6, /* surface function outside the bytecode subset */
   GMLRT_ERR_IO = -7,
   GMLRT_ERR_SCENE_TOO_LARGE = -8,
-  GMLRT_ERR_NOT_INITIALISED = -9
+  GMLRT_ERR_NOT_INITIALISED = -9,
+  GMLRT_ERR_SINK = -10           /* a gmlrt_renderer callback returned non-zero       */
 };
 const char* gmlrt_strerror(int status);
 /* Text of the most recent failure on the calling thread ("" if none). */
@@ -216,6 +217,25 @@ void gmlrt_scene_destroy(gmlrt_scene* s);
  * stream) and the call returns after the kernel has finished; stats as above. */
 int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
                         void* hip_stream, gmlrt_stats* stats);
+
+/* The reference's pixel sink, trait Renderer { new_image, push_pixel, done }
+ * (raytracer.rs:113-117), which render() obtains from RENDERER_FACTORY
+ * (raytracer.rs:183-203, 206-221; the wasm front-end installs a canvas sink through
+ * set_renderer_factory, lib.rs:21-26).  gmlrt_render_to_sink is render() with that
+ * contract kept: new_image(filename, w, h) once, then push_pixel once per pixel with the
+ * unquantised f64 colour, in scanline order, top row first (render_pixels,
+ * raytracer.rs:137-146), then done().  The reference never calls done() at this
+ * snapshot (raytracer.rs:177 has no caller); here it is called, once, after the last
+ * pixel; it may be NULL.  A callback that returns non-zero stops the call with
+ * GMLRT_ERR_SINK.  Callbacks run on the calling thread. */
+typedef struct gmlrt_renderer {
+  void* user;
+  int (*new_image)(void* user, const char* filename, int64_t width, int64_t height);
+  int (*push_pixel)(void* user, const double rgb[3]);
+  int (*done)(void* user);
+} gmlrt_renderer;
+int gmlrt_render_to_sink(const void* blob, size_t blob_bytes, const gmlrt_params* params, const char* filename,
+                         const gmlrt_renderer* sink, gmlrt_stats* stats);
 
 /* Replaces write_ppm_file (raytracer.rs:11-28): "P6 w h 255\n" + w*h*3 bytes. */
 int gmlrt_write_ppm(const char* path, const uint8_t* rgb8, int64_t w, int64_t h);

@@ -55,6 +55,7 @@ const char* gmlrt_strerror(int status) {
     case GMLRT_ERR_IO: return "I/O error";
     case GMLRT_ERR_SCENE_TOO_LARGE: return "scene too large";
     case GMLRT_ERR_NOT_INITIALISED: return "gmlrt_init has not been called";
+    case GMLRT_ERR_SINK: return "a renderer callback reported failure";
     default: return "unknown status";
   }
 }
@@ -258,6 +259,30 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
   total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   total.n_gpus = (uint32_t)n_gpus;
   if (stats) *stats = total;
+  return GMLRT_OK;
+}
+
+int gmlrt_render_to_sink(const void* blob, size_t blob_bytes, const gmlrt_params* params, const char* filename,
+                         const gmlrt_renderer* sink, gmlrt_stats* stats) {
+  if (!sink || !sink->new_image || !sink->push_pixel) return fail(GMLRT_ERR_INVALID_ARG, "sink needs new_image and push_pixel");
+  int rc = check_params(params);
+  if (rc != GMLRT_OK) return rc;
+  const size_t n = (size_t)params->width * (size_t)params->height * 3;
+  std::vector<uint8_t> rgb8;
+  std::vector<double> rgbf;
+  try {
+    rgb8.resize(n);
+    rgbf.resize(n);
+  } catch (std::bad_alloc&) {
+    return fail(GMLRT_ERR_SCENE_TOO_LARGE, "image does not fit in host memory");
+  }
+  rc = gmlrt_render(blob, blob_bytes, params, rgb8.data(), rgbf.data(), stats);
+  if (rc != GMLRT_OK) return rc;
+  if (sink->new_image(sink->user, filename ? filename : "", params->width, params->height) != 0)
+    return fail(GMLRT_ERR_SINK, "new_image failed");
+  for (size_t i = 0; i < n; i += 3)
+    if (sink->push_pixel(sink->user, &rgbf[i]) != 0) return fail(GMLRT_ERR_SINK, "push_pixel failed");
+  if (sink->done && sink->done(sink->user) != 0) return fail(GMLRT_ERR_SINK, "done failed");
   return GMLRT_OK;
 }
 

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GMLRT_LIB") or os.path.join(_HERE, "libgmlrt.so")  # 
 EXPORTS = [
     "gmlrt_strerror", "gmlrt_last_error", "gmlrt_part_rows", "gmlrt_part_row_index", "gmlrt_init",
     "gmlrt_shutdown", "gmlrt_device_count", "gmlrt_render", "gmlrt_scene_create", "gmlrt_scene_destroy",
-    "gmlrt_render_device", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
+    "gmlrt_render_device", "gmlrt_render_to_sink", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
     "gmlrt_program_close", "gmlrt_program_num_renders", "gmlrt_program_render_call",
 ]
 
@@ -43,6 +43,17 @@ class Stats(ctypes.Structure):
     @property
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_reflect
+
+
+NEW_IMAGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64)
+PUSH_PIXEL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double))
+DONE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+
+class Renderer(ctypes.Structure):
+    """gmlrt_renderer: the reference's trait Renderer as C callbacks."""
+    _fields_ = [("user", ctypes.c_void_p), ("new_image", NEW_IMAGE_FN), ("push_pixel", PUSH_PIXEL_FN),
+                ("done", DONE_FN)]
 
 
 class GmlrtError(RuntimeError):
@@ -82,6 +93,8 @@ def lib():
         L.gmlrt_part_row_index.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
         L.gmlrt_init.argtypes = [ctypes.c_int]
         L.gmlrt_render.argtypes = [vp, sz, ctypes.POINTER(Params), vp, vp, ctypes.POINTER(Stats)]
+        L.gmlrt_render_to_sink.argtypes = [vp, sz, ctypes.POINTER(Params), ctypes.c_char_p, ctypes.POINTER(Renderer),
+                                           ctypes.POINTER(Stats)]
         L.gmlrt_scene_create.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(vp)]
         L.gmlrt_scene_destroy.argtypes = [vp]
         L.gmlrt_scene_destroy.restype = None
@@ -180,6 +193,20 @@ def render(call, want_f64=False):
                               f64.ctypes.data_as(ctypes.c_void_p) if want_f64 else None, ctypes.byref(st)),
            "gmlrt_render")
     return rgb8, f64, st
+
+
+def render_to_sink(call, new_image, push_pixel, done=None):
+    """gmlrt_render_to_sink with Python callables: new_image(filename, w, h), push_pixel((r, g, b)), done();
+    a callable that returns a true value stops the render (GMLRT_ERR_SINK)."""
+    if not _inited:
+        init(0)
+    r = Renderer(None, NEW_IMAGE_FN(lambda u, f, w, h: int(bool(new_image(f.decode(), w, h)))),
+                 PUSH_PIXEL_FN(lambda u, p: int(bool(push_pixel((p[0], p[1], p[2]))))),
+                 DONE_FN(lambda u: int(bool(done()))) if done else DONE_FN())
+    st = Stats()
+    _check(lib().gmlrt_render_to_sink(call.blob, len(call.blob), ctypes.byref(call.params), call.filename.encode(),
+                                      ctypes.byref(r), ctypes.byref(st)), "gmlrt_render_to_sink")
+    return st
 
 
 class DeviceScene:

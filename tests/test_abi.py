@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(gmlrt):
 def test_strerror_and_status_codes(gmlrt):
     L = gmlrt.lib()
     assert L.gmlrt_strerror(0) == b"ok"
-    for code in range(-9, 0):
+    for code in range(-10, 0):
         assert L.gmlrt_strerror(code) not in (b"ok", b"unknown status")
     assert L.gmlrt_strerror(-99) == b"unknown status"
 
@@ -172,3 +172,12 @@ def test_other_reference_scenes_flatten(gmlrt, name, renders, leaves):
 def test_failing_programs_fail_cleanly(gmlrt, name):
     with pytest.raises(gmlrt.GmlrtError):
         gmlrt.Program(path=os.path.join(SCENES, name + ".gml"))
+
+
+def test_sink_entry_point_rejects_bad_arguments(gmlrt):
+    # no GPU needed: argument checks come first
+    L = gmlrt.lib()
+    c = gmlrt.Program(path=os.path.join(SCENES, "spheres.gml")).calls[0]
+    assert L.gmlrt_render_to_sink(c.blob, len(c.blob), ctypes.byref(c.params), b"x.ppm", None, None) == -1
+    empty = gmlrt.Renderer()
+    assert L.gmlrt_render_to_sink(c.blob, len(c.blob), ctypes.byref(c.params), b"x.ppm", ctypes.byref(empty), None) == -1

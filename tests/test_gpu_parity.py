@@ -211,3 +211,21 @@ def test_other_reference_scenes_match_oracle(gmlrt, oracle, name):
         both = np.isfinite(f64) & np.isfinite(ref64)
         assert (np.isfinite(f64) == np.isfinite(ref64)).all()
         assert np.abs(f64[both] - ref64[both]).max() <= 1e-9
+
+
+def test_renderer_sink_gets_the_image_pixel_by_pixel(gmlrt):
+    # trait Renderer (raytracer.rs:113-117): new_image once, push_pixel w*h times in scanline order, done once
+    call = gmlrt.Program(path=os.path.join(SCENES, "spheres.gml")).calls[0].with_overrides(64, 48, 2)
+    _, f64, _ = gmlrt.render(call, want_f64=True)
+    log = {"images": [], "pixels": [], "done": 0}
+    st = gmlrt.render_to_sink(call, lambda f, w, h: log["images"].append((f, w, h)),
+                              lambda p: log["pixels"].append(p), lambda: log.__setitem__("done", log["done"] + 1))
+    assert log["images"] == [("spheres.ppm", 64, 48)] and log["done"] == 1
+    assert st.rays_primary == 64 * 48
+    got = np.array(log["pixels"]).reshape(48, 64, 3)
+    assert (got == f64).all()
+    # a sink that gives up after 10 pixels
+    seen = []
+    with pytest.raises(gmlrt.GmlrtError) as e:
+        gmlrt.render_to_sink(call, lambda f, w, h: None, lambda p: seen.append(p) or len(seen) >= 10)
+    assert e.value.status == -10 and len(seen) == 10
