@@ -3,6 +3,7 @@
 // into the caller's framebuffer) and the GML program front-end handle.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -109,6 +110,7 @@ int gmlrt_init(int n_gpus) {
 void gmlrt_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_n_gpus = 0;
+  gmlrt::dev_release_cached();
 }
 
 static int check_params(const gmlrt_params* p) {
@@ -185,17 +187,22 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
   const int32_t tile_rows = params->tile_rows > 0 ? params->tile_rows : 8;
   // no point in giving a GPU nothing to do
   const int64_t n_tiles = (h + tile_rows - 1) / tile_rows;
+  // GMLRT_EMULATE_PARTS=N splits the frame into N partitions however many GPUs there are (partition g
+  // runs on GPU g mod n): the multi-GPU path of this function on a box with one GPU, for tests.
+  const int real_gpus = n_gpus;
+  if (const char* e = std::getenv("GMLRT_EMULATE_PARTS")) {
+    const int n = std::atoi(e);
+    if (n >= 1 && n <= 64) n_gpus = n;
+  }
   if ((int64_t)n_gpus > n_tiles) n_gpus = (int)n_tiles;
 
   struct PerGpu {
     std::string err;
     gmlrt_stats st;
-    std::vector<uint8_t> rgb8;
-    std::vector<double> rgbf;
-    std::vector<int64_t> rows;
   };
   std::vector<PerGpu> per((size_t)n_gpus);
   auto work = [&](int g) {
+    const int dev = g % real_gpus;
     PerGpu& P = per[(size_t)g];
     std::memset(&P.st, 0, sizeof(P.st));
     gmlrt_params p = *params;
@@ -204,33 +211,42 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
     p.part = g;
     p.nparts = n_gpus;
     const int64_t rows = gmlrt_part_rows(h, tile_rows, g, n_gpus);
-    P.rows.resize((size_t)rows);
-    gmlrt_part_row_index(h, tile_rows, g, n_gpus, P.rows.data());
     gmlrt::DeviceScene ds;
     void *d8 = nullptr, *df = nullptr;
+    const bool verbose = std::getenv("GMLRT_VERBOSE") != nullptr;
+    auto tick = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
+      if (!verbose) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[gmlrt] gpu %d %s: %.2f ms\n", g, what, std::chrono::duration<double, std::milli>(now - last).count());
+      last = now;
+    };
     do {
-      P.err = gmlrt::dev_scene_create(blob, blob_bytes, g, &ds);
+      P.err = gmlrt::dev_scene_create(blob, blob_bytes, dev, &ds);
       if (!P.err.empty()) break;
+      ds.learn_order = false;  // this handle renders once
+      tick("scene upload");
       const size_t n8 = (size_t)rows * (size_t)w * 3;
-      P.err = gmlrt::dev_alloc(g, n8, &d8);
+      P.err = gmlrt::dev_alloc(dev, n8, &d8);
       if (!P.err.empty()) break;
       if (rgbf64) {
-        P.err = gmlrt::dev_alloc(g, n8 * sizeof(double), &df);
+        P.err = gmlrt::dev_alloc(dev, n8 * sizeof(double), &df);
         if (!P.err.empty()) break;
       }
+      tick("output buffers");
       P.err = gmlrt::dev_render(&ds, p, d8, df, nullptr, &P.st);
       if (!P.err.empty()) break;
-      P.rgb8.resize(n8);
-      P.err = gmlrt::dev_copy_to_host(g, P.rgb8.data(), d8, n8);
+      tick("render (workspace + kernel)");
+      // the final gather: each GPU's rows go straight to their place in the caller's framebuffer
+      P.err = gmlrt::dev_copy_rows_to_host(dev, rgb8, d8, (size_t)w * 3, h, tile_rows, g, n_gpus);
       if (!P.err.empty()) break;
-      if (rgbf64) {
-        P.rgbf.resize(n8);
-        P.err = gmlrt::dev_copy_to_host(g, P.rgbf.data(), df, n8 * sizeof(double));
-      }
+      if (rgbf64)
+        P.err = gmlrt::dev_copy_rows_to_host(dev, rgbf64, df, (size_t)w * 3 * sizeof(double), h, tile_rows, g, n_gpus);
     } while (false);
-    gmlrt::dev_free(g, d8);
-    gmlrt::dev_free(g, df);
+    tick("copy to host");
+    gmlrt::dev_free(dev, d8);
+    gmlrt::dev_free(dev, df);
     gmlrt::dev_scene_destroy(&ds);
+    tick("free");
   };
   if (n_gpus == 1) {
     work(0);
@@ -243,12 +259,6 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
   std::memset(&total, 0, sizeof(total));
   for (auto& P : per) {
     if (!P.err.empty()) return fail(GMLRT_ERR_HIP, P.err);
-    // the final gather: each GPU's rows go to their place in the caller's framebuffer
-    const size_t row8 = (size_t)w * 3;
-    for (size_t k = 0; k < P.rows.size(); k++) {
-      std::memcpy(rgb8 + (size_t)P.rows[k] * row8, P.rgb8.data() + k * row8, row8);
-      if (rgbf64) std::memcpy(rgbf64 + (size_t)P.rows[k] * row8, P.rgbf.data() + k * row8, row8 * sizeof(double));
-    }
     total.rays_primary += P.st.rays_primary;
     total.rays_shadow += P.st.rays_shadow;
     total.rays_reflect += P.st.rays_reflect;

@@ -74,6 +74,7 @@ struct DeviceScene {
   void* d_tile_order = nullptr; // u32 per tile: tiles sorted by decreasing cost
   size_t tiles_alloc = 0;
   bool order_valid = false;     // d_tile_order holds an order for order_key
+  bool learn_order = true;      // false for a handle that renders once: learning would never pay
   int order_state = 0;          // 0: nothing learnt, 1: order built, on trial in the next launch, 2: decided
   bool order_use = false;       // the trial launch was faster than the one in image order
   float order_base_ms = 0.f;    // kernel time of the launch in image order
@@ -94,5 +95,11 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
 std::string dev_alloc(int device, size_t bytes, void** out);
 void dev_free(int device, void* p);
 std::string dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
+// Copies the packed rows one partition rendered (device) to their places in the full image (host):
+// partition `part` of `nparts` owns the row tiles part, part + nparts, ... of `tile_rows` rows each.
+std::string dev_copy_rows_to_host(int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
+                                  int32_t tile_rows, int32_t part, int32_t nparts);
+// Frees what dev_scene_destroy keeps for the next scene on the same device (scratch buffers, events).
+void dev_release_cached(void);
 
 }  // namespace gmlrt

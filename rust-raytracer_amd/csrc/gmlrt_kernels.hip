@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -544,8 +545,63 @@ std::string dev_copy_to_host(int device, void* dst, const void* src, size_t byte
   return "";
 }
 
+std::string dev_copy_rows_to_host(int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
+                                  int32_t tile_rows, int32_t part, int32_t nparts) {
+  HIP_TRY(hipSetDevice(device));
+  const int64_t rows = gmlrt_part_rows(height, tile_rows, part, nparts);
+  if (rows <= 0) return "";
+  if (nparts <= 1) {
+    HIP_TRY(hipMemcpy(image, d_rows, (size_t)rows * row_bytes, hipMemcpyDeviceToHost));
+    return "";
+  }
+  // full tiles in one strided copy, a ragged last tile after it
+  const size_t band = (size_t)tile_rows * row_bytes;
+  const int64_t full = rows / tile_rows, rest = rows % tile_rows;
+  uint8_t* dst = (uint8_t*)image + (size_t)part * band;
+  if (full > 0)
+    HIP_TRY(hipMemcpy2D(dst, (size_t)nparts * band, d_rows, band, band, (size_t)full, hipMemcpyDeviceToHost));
+  if (rest > 0)
+    HIP_TRY(hipMemcpy(dst + (size_t)full * (size_t)nparts * band, (const uint8_t*)d_rows + (size_t)full * band,
+                      (size_t)rest * row_bytes, hipMemcpyDeviceToHost));
+  return "";
+}
+
+namespace {
+// Scratch of the last destroyed scene per device (event stacks, context records, counters, tile
+// tables, timing events): allocating gigabytes of address space per render call costs milliseconds.
+std::mutex g_spare_mu;
+std::vector<DeviceScene> g_spare;
+
+void free_workspace(DeviceScene* s) {
+  (void)hipFree(s->d_ev_dist);
+  (void)hipFree(s->d_ev_meta);
+  (void)hipFree(s->d_ctx);
+  (void)hipFree(s->d_counters);
+  (void)hipFree(s->d_tile_cost);
+  (void)hipFree(s->d_tile_order);
+  if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
+  if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
+}
+}  // namespace
+
+void dev_release_cached(void) {
+  std::lock_guard<std::mutex> lk(g_spare_mu);
+  for (auto& w : g_spare)
+    if (hipSetDevice(w.device) == hipSuccess) free_workspace(&w);
+  g_spare.clear();
+}
+
 std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceScene* out) {
   HIP_TRY(hipSetDevice(device));
+  {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    for (size_t i = 0; i < g_spare.size(); i++)
+      if (g_spare[i].device == device) {
+        *out = g_spare[i];
+        g_spare.erase(g_spare.begin() + (long)i);
+        break;
+      }
+  }
   out->device = device;
   out->blob_bytes = bytes;
   std::memcpy(&out->hdr, blob, sizeof(out->hdr));
@@ -577,12 +633,14 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     HIP_TRY(hipMalloc(&out->d_leaf_surf, leaf_surf.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(out->d_leaf_surf, leaf_surf.data(), leaf_surf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMalloc(&out->d_counters, 512));
-  hipEvent_t a, b;
-  HIP_TRY(hipEventCreate(&a));
-  HIP_TRY(hipEventCreate(&b));
-  out->ev_start = a;
-  out->ev_stop = b;
+  if (!out->d_counters) HIP_TRY(hipMalloc(&out->d_counters, 512));
+  if (!out->ev_start) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    out->ev_start = a;
+    out->ev_stop = b;
+  }
   return "";
 }
 
@@ -591,16 +649,24 @@ void dev_scene_destroy(DeviceScene* s) {
   if (hipSetDevice(s->device) != hipSuccess) return;
   (void)hipFree(s->d_blob);
   (void)hipFree(s->d_prog);
-  (void)hipFree(s->d_tile_cost);
-  (void)hipFree(s->d_tile_order);
   (void)hipFree(s->d_surf);
   (void)hipFree(s->d_leaf_surf);
-  (void)hipFree(s->d_ev_dist);
-  (void)hipFree(s->d_ev_meta);
-  (void)hipFree(s->d_ctx);
-  (void)hipFree(s->d_counters);
-  if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
-  if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
+  // the scratch stays for the next scene on this device (one set per device)
+  DeviceScene spare;
+  spare.device = s->device;
+  spare.d_ev_dist = s->d_ev_dist; spare.d_ev_meta = s->d_ev_meta; spare.d_ctx = s->d_ctx;
+  spare.d_counters = s->d_counters;
+  spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc; spare.lanes_alloc = s->lanes_alloc;
+  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.tiles_alloc = s->tiles_alloc;
+  spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
+  bool kept = false;
+  {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    bool have = false;
+    for (auto& w : g_spare) have = have || w.device == spare.device;
+    if (!have) { g_spare.push_back(spare); kept = true; }
+  }
+  if (!kept) free_workspace(&spare);
   *s = DeviceScene{};
 }
 
@@ -743,7 +809,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   static const bool no_order = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
   const bool ordered = s->order_valid && !no_order && (s->order_state == 1 || (s->order_state == 2 && s->order_use));
   A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
-  A.tile_cost = s->order_state == 0 && !no_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
+  A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
   A.next_slot = (unsigned int*)s->d_counters;
   A.ray_counts = (unsigned long long*)((uint8_t*)s->d_counters + 8);
   A.diag = (unsigned long long*)((uint8_t*)s->d_counters + 64);
@@ -787,7 +853,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     // for a shorter tail; scenes with evenly priced tiles lose)
     s->order_use = ms < 0.98f * s->order_base_ms;
     s->order_state = 2;
-  } else if (s->order_state == 0 && !no_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
+  } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
     // first launch with this geometry: turn its per-tile costs into the order of the next ones
     // (worth it only when a wave renders several tiles)
     std::vector<uint32_t> cost(n_tiles), order(n_tiles);

@@ -229,3 +229,16 @@ def test_renderer_sink_gets_the_image_pixel_by_pixel(gmlrt):
     with pytest.raises(gmlrt.GmlrtError) as e:
         gmlrt.render_to_sink(call, lambda f, w, h: None, lambda p: seen.append(p) or len(seen) >= 10)
     assert e.value.status == -10 and len(seen) == 10
+
+
+def test_in_process_multi_gpu_path_on_one_gpu(gmlrt, monkeypatch):
+    # gmlrt_render with the frame split into partitions (one host thread each, strided copies straight into the
+    # caller's buffers); GMLRT_EMULATE_PARTS runs every partition on the GPU that is there
+    call = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0].with_overrides(203, 117, 3)
+    ref, ref64, st0 = gmlrt.render(call, want_f64=True)
+    for parts in ("2", "3", "8"):
+        monkeypatch.setenv("GMLRT_EMULATE_PARTS", parts)
+        img, f64, st = gmlrt.render(call, want_f64=True)
+        assert (img == ref).all() and (f64 == ref64).all(), parts
+        assert st.rays == st0.rays and st.n_gpus == int(parts)
+    monkeypatch.delenv("GMLRT_EMULATE_PARTS")
