@@ -80,6 +80,7 @@ struct KArgs {
   uint32_t vm_lds_off;   // byte offset of that LDS region (after the operand-stack lengths)
   uint32_t lds_ctx;      // 1: the region also holds the hot fields of the shading context
   const uint32_t* tile_order;  // tile to render for the i-th hand-out; null: i itself
+  unsigned long long* tile_dbg;  // diagnostic build only: per tile, 4 counters
   uint32_t* tile_cost;         // per tile: how long its wave spent on it (wall-clock ticks); null: not wanted
   unsigned int* next_slot;
   unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
@@ -111,7 +112,7 @@ struct ShadeArgs {
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
 // where the cycles went.  Never part of the shipped library; numbers from it are
 // shares, not timings.
-struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes; };
+struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes, n_redo; };
 #ifdef GMLRT_DIAG
 #define DIAG(...) __VA_ARGS__
 #else
@@ -195,6 +196,92 @@ __device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__
     evM[(size_t)(a0 + n) * kWave] = evM[(size_t)(out0 + n) * kWave];
   }
   return k;
+}
+
+// The same for short lists (1..4 events each), which is nearly all of them: every event is
+// fetched up front with independent loads, merged and swept in registers, and the output
+// written straight over A.  merge_lists above walks the lists in memory, one dependent load
+// after the other; on a frontier child with a dozen nested operators that chain of round
+// trips was the longest thing a ray could wait for.
+//
+// Order: the reference sorts the concatenation A ++ B stably by distance, i.e. by the total
+// order (distance, position in A ++ B).  Both halves arrive sorted in that order (padding:
+// +infinity), so Batcher's odd-even merge network for 4 + 4 elements yields exactly that
+// sequence.  The position travels in three free bits of the meta word.
+constexpr uint32_t kPosShift = 25;  // bits 27..25 of a meta word, free in event storage
+__device__ inline void merge_cx(double& d0, uint32_t& m0, double& d1, uint32_t& m1) {
+  const bool swap = d0 > d1 || (d0 == d1 && (m0 >> kPosShift) > (m1 >> kPosShift));
+  const double dl = swap ? d1 : d0, dh = swap ? d0 : d1;
+  const uint32_t ml = swap ? m1 : m0, mh = swap ? m0 : m1;
+  d0 = dl; d1 = dh; m0 = ml; m1 = mh;
+}
+__device__ __noinline__ uint32_t merge_small(uint32_t rule, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
+                                             uint32_t a0, uint32_t la, uint32_t lb) {
+  double* __restrict__ evD = global_space(evD_v);
+  uint32_t* __restrict__ evM = global_space(evM_v);
+  const uint32_t b0 = a0 + la;
+  double d[8];
+  uint32_t m[8];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    // clamped index: always a slot of the list, so all sixteen loads can be in flight together
+    const uint32_t ia = a0 + (i < la ? i : la - 1u), ib = b0 + (i < lb ? i : lb - 1u);
+    d[i] = evD[(size_t)ia * kWave];
+    m[i] = evM[(size_t)ia * kWave];
+    d[4 + i] = evD[(size_t)ib * kWave];
+    m[4 + i] = evM[(size_t)ib * kWave];
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    if (i >= la) d[i] = __builtin_inf();
+    if (i >= lb) d[4 + i] = __builtin_inf();
+    m[i] = (m[i] & ~(7u << kPosShift)) | (i << kPosShift);
+    m[4 + i] = (m[4 + i] & ~(7u << kPosShift)) | ((4u + i) << kPosShift);
+  }
+  merge_cx(d[0], m[0], d[4], m[4]); merge_cx(d[1], m[1], d[5], m[5]);
+  merge_cx(d[2], m[2], d[6], m[6]); merge_cx(d[3], m[3], d[7], m[7]);
+  merge_cx(d[2], m[2], d[4], m[4]); merge_cx(d[3], m[3], d[5], m[5]);
+  merge_cx(d[1], m[1], d[2], m[2]); merge_cx(d[3], m[3], d[4], m[4]); merge_cx(d[5], m[5], d[6], m[6]);
+  // the sweep of primitives.rs:262-313, as in merge_lists
+  const uint32_t total = la + lb;
+  uint32_t k = 0;
+  bool in1 = false, in2 = false, inside = false;
+  double prevt = 0.0;
+#pragma unroll
+  for (uint32_t n = 0; n < 8; n++) {
+    if (n < total) {
+      const bool from_b = ((m[n] >> kPosShift) & 4u) != 0;
+      const uint32_t mm = m[n] & ~(7u << kPosShift);
+      const bool entry = !(mm & kCurExit);
+      if (from_b) in2 = entry; else in1 = entry;
+      const bool ni = csg_rule(rule, in1, in2);
+      if (inside && !ni) {
+        if (d[n] - prevt < 1e-10) {
+          k--;  // sliver: drop the Entry that opened it
+        } else {
+          evD[(size_t)(a0 + k) * kWave] = d[n];
+          evM[(size_t)(a0 + k) * kWave] = mm | kCurExit;
+          k++;
+        }
+      }
+      if (!inside && ni) {
+        evD[(size_t)(a0 + k) * kWave] = d[n];
+        evM[(size_t)(a0 + k) * kWave] = mm & ~kCurExit;
+        k++;
+        prevt = d[n];
+      }
+      inside = ni;
+    }
+  }
+  return k;
+}
+__device__ inline uint32_t merge_any(uint32_t rule, double* __restrict__ evD, uint32_t* __restrict__ evM, uint32_t a0,
+                                     uint32_t la, uint32_t lb) {
+  uint32_t out = 0;
+  const bool small = la <= 4u && lb <= 4u;
+  if (small) out = merge_small(rule, evD, evM, a0, la, lb);
+  else out = merge_lists(rule, evD, evM, a0, la, lb);
+  return out;
 }
 
 // Node::intersect of the whole scene for one ray per lane, every operator evaluated
@@ -287,7 +374,7 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
           else general = true;
         }
       }
-      if (general) lout = merge_lists(rule, evD, evM, a0, la, lb);
+      if (general) lout = merge_any(rule, evD, evM, a0, la, lb);
       lens[(level - 2) * kBlock + tid] = (uint16_t)lout;
       sp = a0 + lout;
       level--;
@@ -410,7 +497,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   // order (dearest first) of later launches with the same geometry.
   uint32_t cur_tile = 0xFFFFFFFFu;
   unsigned long long tile_t0 = 0;
-  Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  DIAG(unsigned long long dbg_trav0 = 0, dbg_leaf0 = 0, dbg_merge0 = 0, dbg_redo0 = 0;)
+  Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   DIAG(unsigned long long t0 = __builtin_readcyclecounter(); const unsigned long long w_start = wall_clock64();
        unsigned long long w_tiles = 0;)
 
@@ -425,6 +513,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         const unsigned long long now = A.tile_cost ? wall_clock64() : 0ull;
         if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(now - tile_t0);
+        DIAG(if (cur_tile != 0xFFFFFFFFu && lane == 0 && A.tile_dbg) {
+               A.tile_dbg[cur_tile * 4 + 0] = dg.n_trav - dbg_trav0; A.tile_dbg[cur_tile * 4 + 1] = dg.n_leaf - dbg_leaf0;
+               A.tile_dbg[cur_tile * 4 + 2] = dg.n_merge - dbg_merge0; A.tile_dbg[cur_tile * 4 + 3] = dg.n_redo - dbg_redo0; }
+             dbg_trav0 = dg.n_trav; dbg_leaf0 = dg.n_leaf; dbg_merge0 = dg.n_merge; dbg_redo0 = dg.n_redo;)
         cur_tile = 0xFFFFFFFFu;
         if (t >= A.n_slots) { more = false; break; }
         tile_base = t;
@@ -470,6 +562,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- one scene traversal for whatever ray each lane holds
     Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if (__ballot(h.redo)) {
+      DIAG(dg.n_redo++;)
       // a primitive right under the root's unions gave a span shorter than 1e-10: only the
       // full sweep knows whether it survives (primitives.rs:295-298)
       const Hit g = intersect_general(leaves, nodes, bounds, A.n_nodes, A.n_leaves, h.redo, S.o, S.d, evD, evM, lens);
@@ -752,6 +845,10 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.n_vm_fast = (uint32_t)n_vm_fast;
   A.vm_lds_off = (uint32_t)lens_bytes;
   uint64_t grid = (uint64_t)prop.multiProcessorCount * (uint64_t)blocks_per_cu;
+  if (const char* e = std::getenv("GMLRT_GRID_BLOCKS")) {  // tuning runs
+    const long v = std::atol(e);
+    if (v > 0 && (uint64_t)v < grid) grid = (uint64_t)v;
+  }
   const uint64_t need = (n_slots + kBlock - 1) / kBlock;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
@@ -810,6 +907,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   const bool ordered = s->order_valid && !no_order && (s->order_state == 1 || (s->order_state == 2 && s->order_use));
   A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
   A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
+#ifdef GMLRT_DIAG
+  unsigned long long* d_tile_dbg = nullptr;
+  HIP_TRY(hipMalloc(&d_tile_dbg, n_tiles * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_tile_dbg, 0, n_tiles * 4 * sizeof(unsigned long long), stream));
+  A.tile_dbg = d_tile_dbg;
+#endif
   A.next_slot = (unsigned int*)s->d_counters;
   A.ray_counts = (unsigned long long*)((uint8_t*)s->d_counters + 8);
   A.diag = (unsigned long long*)((uint8_t*)s->d_counters + 64);
@@ -862,6 +965,32 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     // neighbouring tiles walk the same parts of the scene program, and waves that run side by side
     // should keep sharing them in cache.
     static const uint32_t n_classes = [] { const char* e = std::getenv("GMLRT_TILE_CLASSES"); return e ? (uint32_t)std::atoi(e) : 16u; }();
+    if (std::getenv("GMLRT_VERBOSE")) {
+      std::vector<uint32_t> sorted(cost);
+      std::sort(sorted.begin(), sorted.end());
+      size_t at = 0;
+      for (size_t i = 0; i < n_tiles; i++) if (cost[i] > cost[at]) at = i;
+      unsigned long long sum = 0;
+      for (uint32_t c : cost) sum += c;
+      std::fprintf(stderr, "[gmlrt] tile cost (us, 100 MHz clock): p50 %.1f p90 %.1f p99 %.1f max %.1f (tile x %zu y %zu), sum %.0f over %zu tiles\n",
+                   sorted[n_tiles / 2] / 100.0, sorted[n_tiles * 9 / 10] / 100.0, sorted[n_tiles * 99 / 100] / 100.0,
+                   cost[at] / 100.0, at % A.tiles_x, at / A.tiles_x, (double)sum / 100.0, n_tiles);
+#ifdef GMLRT_DIAG
+      {
+        std::vector<unsigned long long> dbg(n_tiles * 4);
+        HIP_TRY(hipMemcpy(dbg.data(), d_tile_dbg, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<size_t> idx(n_tiles);
+        for (size_t i = 0; i < n_tiles; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+        for (size_t r = 0; r < 12 && r < n_tiles; r++) {
+          const size_t q = idx[r * (r < 6 ? 1 : n_tiles / 40)];
+          std::fprintf(stderr, "[gmlrt diag] tile rank %zu (x %zu y %zu): %.1f us, traversals %llu, leaves %llu, merges %llu, redo %llu\n",
+                       r < 6 ? r : r * (n_tiles / 40), q % A.tiles_x, q / A.tiles_x, cost[q] / 100.0, dbg[q * 4], dbg[q * 4 + 1],
+                       dbg[q * 4 + 2], dbg[q * 4 + 3]);
+        }
+      }
+#endif
+    }
     uint32_t top = 1;
     for (size_t i = 0; i < n_tiles; i++) top = std::max(top, cost[i]);
     for (size_t i = 0; i < n_tiles; i++) {

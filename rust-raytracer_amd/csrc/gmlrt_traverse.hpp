@@ -173,7 +173,7 @@ __device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, con
         }
       }
       DIAG(if (__ballot(general)) dg.n_merge++;)
-      if (general) lout = merge_lists(rule, evD, evM, a0, la, lb);
+      if (general) lout = merge_any(rule, evD, evM, a0, la, lb);
       lens[(level - 2) * kBlock + tid] = (uint16_t)lout;
       sp = a0 + lout;
       level--;
