@@ -444,9 +444,9 @@ struct LaneState {
   V3 o, d;       // ray to traverse
   float t_stop;  // the traversal may stop at the first hit at or before this distance (-inf: never)
   uint32_t pix;  // output index (row-in-partition * w + x)
-  uint32_t st;   // bits 1..0 RayKind, 12..2 bounce level, 23..13 light being tested,
-                 // 24 / 25 / 26: after_traversal spawned a shadow ray / a bounce / shaded a hit
+  uint32_t st;   // bits 1..0 RayKind, 12..2 bounce level, 23..13 light being tested
 };
+// what one call of after_traversal did: spawned a shadow ray / a bounce / shaded a hit
 constexpr uint32_t kStShadow = 1u << 24, kStReflect = 1u << 25, kStHit = 1u << 26;
 __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 
@@ -464,6 +464,9 @@ __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 #ifndef GMLRT_WAVES_PER_SIMD
 #define GMLRT_WAVES_PER_SIMD 4  // measured on chess 4K depth 5: 3 -> 1796, 4 -> 1955, 5 -> 1655, 6 -> 1794 Mrays/s
 #endif
+// kLdsCtx: the block's LDS has room for the hot fields of the shading context (see gmlrt_shade.hpp);
+// a kernel per case, so that the loop below holds a single call site of after_traversal.
+template <bool kLdsCtx>
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
@@ -572,12 +575,11 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;)
     if (st_kind(S.st) != kIdle) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
-      if (A.lds_ctx) S = after_traversal<true>(S, h.dist, hm, shade_args, ctx, vm_fast);
-      else S = after_traversal<false>(S, h.dist, hm, shade_args, ctx, vm_fast);
-      n_shadow += (S.st >> 24) & 1u;
-      n_reflect += (S.st >> 25) & 1u;
-      n_hits += (S.st >> 26) & 1u;
-      S.st &= 0x00FFFFFFu;
+      uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
+      S = after_traversal<kLdsCtx>(S, h.dist, hm, shade_args, ctx, vm_fast, &events);
+      n_shadow += (events >> 24) & 1u;
+      n_reflect += (events >> 25) & 1u;
+      n_hits += (events >> 26) & 1u;
     }
     DIAG(t0 = __builtin_readcyclecounter(); dg.t_after += t0 - t2;)
   }
@@ -821,7 +823,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   const size_t lens_bytes = (((size_t)H.max_stack * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
   if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
   int blocks_per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, kBlock, lens_bytes));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<true>, kBlock, lens_bytes));
   if (blocks_per_cu < 1) blocks_per_cu = 1;
   // The surface bytecode's registers go to whatever LDS is left at that occupancy.
   size_t n_vm_fast = s->n_vm_regs;
@@ -942,8 +944,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
 #endif
   HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                     d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
+  if (A.lds_ctx)
+    hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
+  else
+    hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   unsigned long long counts[4] = {0, 0, 0, 0};

@@ -29,10 +29,18 @@ __device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD
 // The traversal result travels as two scalars (distance; meta with kHitAny set when
 // there is a hit): together with the lane state an aggregate would exceed what the
 // calling convention passes in registers and go through the stack.
+//
+// What the call did (kStShadow / kStReflect / kStHit) is written through events_out, which
+// points at a local variable of the caller, on purpose: a call that is handed the address of
+// one of its caller's stack slots cannot be marked as a tail call, and only then may the
+// compiler treat this function (internal, not recursive) as one that preserves no registers.
+// Without that it saves and restores every callee-saved register it touches, about fifty
+// VGPRs to scratch memory and three dozen SGPRs, on every call; with it the caller spills
+// only the handful of values it really keeps across the call.
 template <bool kLds>
 __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
                                                   const ShadeArgs* __restrict__ SA_v, double* __restrict__ ctx_v,
-                                                  uint64_t* __restrict__ vm_fast_v) {
+                                                  uint64_t* __restrict__ vm_fast_v, uint32_t* __restrict__ events_out) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
   double* __restrict__ ctx = global_space(ctx_v);
   constexpr size_t kHotStride = kLds ? (size_t)kBlock : (size_t)kWave;
@@ -247,6 +255,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
          dq[0] += tq1 - tq0; dq[1] += tq2 - tq1; dq[2] += tq3 - tq2; dq[3] += tq4 - tq3; dq[4] += tq5 - tq4;
          dq[5] += tq6 - tq5; dq[6] += tq_runs; dq[7] += tq_lanes;
        })
-  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | events;
+  *events_out = events;
+  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13);
   return S;
 }

@@ -15,7 +15,10 @@
 //   lane has such a candidate it stops taking part, and bounds are skipped by the wave
 //   once no lane is left that needs them.  Camera and bounce rays pass -infinity.
 
-__device__ inline Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
+#ifndef GMLRT_TRAVERSE_INLINE
+#define GMLRT_TRAVERSE_INLINE inline
+#endif
+__device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
                                       uint32_t n_leaves, bool active, V3 o, V3 d, const double t_stop,
                                       double* __restrict__ evD, uint32_t* __restrict__ evM,
                                       uint16_t* __restrict__ lens, Diag& dg) {
