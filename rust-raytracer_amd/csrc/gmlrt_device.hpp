@@ -43,10 +43,12 @@ struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags),
 };
 static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
 std::vector<uint8_t> derive_stream_program(const void* blob);
-// Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h), one per distinct
-// (code, constants) pair among the leaves; leaf_surf[leaf] = index of the leaf's first
-// record, or kNoSurfProg for a constant surface.
+// Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h): every leaf's program
+// specialised for each face its primitive can report, identical results stored once;
+// leaf_surf[leaf * kSurfFaces + face] = index of the first record of the program to run for a
+// hit on that face, or kNoSurfProg for a constant surface.
 constexpr uint32_t kNoSurfProg = 0xFFFFFFFFu;
+constexpr uint32_t kSurfFaces = 8;  // slots per leaf (a cube has six faces)
 std::vector<uint8_t> derive_surface_stream(const void* blob, std::vector<uint32_t>* leaf_surf);
 
 // Device-resident copy of one scene blob plus the per-device scratch the render

@@ -104,7 +104,7 @@ struct ShadeArgs {
   const gmlrt_light* lights;
   const uint64_t* code;
   const uint64_t* consts;
-  const uint32_t* leaf_surf;   // per leaf: first record of its expanded surface program
+  const uint32_t* leaf_surf;   // per leaf and face (kSurfFaces slots a leaf): first record of the surface program to run
   const SurfInstr* surf_prog;  // expanded surface programs
   unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
 };

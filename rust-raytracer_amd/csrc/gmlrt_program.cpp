@@ -35,6 +35,8 @@
 #include <vector>
 
 #include <map>
+#include <string>
+#include <tuple>
 
 #include "gmlrt_device.hpp"
 #include "gmlrt_scene.hpp"
@@ -378,17 +380,47 @@ std::vector<uint8_t> derive_surface_stream(const void* blob, std::vector<uint32_
   const uint64_t* code = (const uint64_t*)(base + H.off_code);
   const uint64_t* consts = (const uint64_t*)(base + H.off_consts);
   std::vector<uint8_t> out;
-  std::map<std::pair<uint32_t, uint32_t>, uint32_t> seen;
-  leaf_surf->assign(H.n_leaves, kNoSurfProg);
+  // (code, constants, face) -> first record; and record bytes -> first record, so that programs
+  // that come out the same (a function that never looks at `face`, two faces that take the same
+  // arm) are stored and, more to the point, run once per wave
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> seen;
+  std::map<std::string, uint32_t> by_content;
+  leaf_surf->assign((size_t)H.n_leaves * kSurfFaces, kNoSurfProg);
   for (uint32_t i = 0; i < H.n_leaves; i++) {
     if (leaves[i].surf_code == GMLRT_SURF_CONST) continue;
-    const auto key = std::make_pair(leaves[i].surf_code, leaves[i].surf_const);
-    auto it = seen.find(key);
-    if (it == seen.end()) {
-      it = seen.emplace(key, (uint32_t)(out.size() / sizeof(SurfInstr))).first;
-      expand_surface(code + key.first, consts + key.second, out);
+    // faces a primitive of this type can report (primitives.rs:403-412, 544-555, 726-734, 897-904, 989-996)
+    const uint32_t n_faces = leaves[i].type == GMLRT_CUBE ? 6u : leaves[i].type == GMLRT_CYLINDER ? 3u
+                             : leaves[i].type == GMLRT_CONE ? 2u : 1u;
+    std::vector<uint8_t> general;
+    for (uint32_t f = 0; f < n_faces; f++) {
+      const auto key = std::make_tuple(leaves[i].surf_code, leaves[i].surf_const, f);
+      auto it = seen.find(key);
+      if (it == seen.end()) {
+        if (general.empty()) expand_surface(code + leaves[i].surf_code, consts + leaves[i].surf_const, general);
+        std::vector<uint8_t> spec;
+        specialize_surface(general.data(), (int64_t)f, spec);
+        const std::string bytes((const char*)spec.data(), spec.size());
+        auto ct = by_content.find(bytes);
+        if (ct == by_content.end()) {
+          ct = by_content.emplace(bytes, (uint32_t)(out.size() / sizeof(SurfInstr))).first;
+          out.insert(out.end(), spec.begin(), spec.end());
+        }
+        it = seen.emplace(key, ct->second).first;
+      }
+      (*leaf_surf)[(size_t)i * kSurfFaces + f] = it->second;
     }
-    (*leaf_surf)[i] = it->second;
+  }
+  if (std::getenv("GMLRT_VERBOSE")) {
+    size_t general_records = 0;
+    std::map<std::pair<uint32_t, uint32_t>, int> distinct;
+    for (uint32_t i = 0; i < H.n_leaves; i++)
+      if (leaves[i].surf_code != GMLRT_SURF_CONST && distinct.emplace(std::make_pair(leaves[i].surf_code, leaves[i].surf_const), 0).second) {
+        std::vector<uint8_t> g;
+        expand_surface(code + leaves[i].surf_code, consts + leaves[i].surf_const, g);
+        general_records += g.size() / sizeof(SurfInstr);
+      }
+    std::fprintf(stderr, "[gmlrt] surface programs: %zu as compiled (%zu records), %zu after specialising per face (%zu records)\n",
+                 distinct.size(), general_records, by_content.size(), out.size() / sizeof(SurfInstr));
   }
   if (out.empty()) out.resize(sizeof(SurfInstr), 0);  // a lone END record: never run, keeps the buffer non-empty
   return out;

@@ -541,6 +541,140 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
   surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, out, R);
 }
 
+// ---- specialisation of an expanded program for one value of `face`.
+// The face index is the one input of a surface function with a handful of values, and scene
+// files branch on it at the top (`face 0 eqi { side } { caps } if`): both arms are in the
+// program, joined by SELECT.  With face known the comparison folds, the SELECT turns into a
+// move and the arm not taken is dead code.  Folding uses the interpreter's own scalar
+// functions and leaves out the libm-class operations (sin, cos, asin, acos), whose last bit
+// may differ between host and device; everything else is IEEE-exact on both.
+namespace {
+// which of a, b, c an operation reads
+void surf_reads(uint32_t op, bool r[3]) {
+  r[0] = r[1] = r[2] = false;
+  switch (op) {
+    case GMLRT_SOP_END: return;
+    case GMLRT_SOP_MOV: case GMLRT_SOP_REAL: case GMLRT_SOP_FLOOR: case GMLRT_SOP_SQRT: case GMLRT_SOP_FRAC:
+    case GMLRT_SOP_CLAMPF: case GMLRT_SOP_SIN: case GMLRT_SOP_COS: case GMLRT_SOP_ASIN: case GMLRT_SOP_ACOS:
+      r[0] = true; return;
+    case GMLRT_SOP_SELECT: case GMLRT_SOP_OUT: r[0] = r[1] = r[2] = true; return;
+    default: r[0] = r[1] = true; return;
+  }
+}
+bool surf_fold(uint32_t op, uint64_t a, uint64_t b, uint64_t* res) {
+  const double fa = vm_as_f64(a), fb = vm_as_f64(b);
+  const int64_t ia = (int64_t)a, ib = (int64_t)b;
+  switch (op) {
+    case GMLRT_SOP_MOV: *res = a; return true;
+    case GMLRT_SOP_ADDI: *res = a + b; return true;
+    case GMLRT_SOP_SUBI: *res = a - b; return true;
+    case GMLRT_SOP_MULI: *res = a * b; return true;
+    case GMLRT_SOP_DIVI: *res = (uint64_t)vm_divi(ia, ib); return true;
+    case GMLRT_SOP_MODI: *res = (uint64_t)vm_modi(ia, ib); return true;
+    case GMLRT_SOP_EQI: *res = ia == ib; return true;
+    case GMLRT_SOP_LESSI: *res = ia < ib; return true;
+    case GMLRT_SOP_REAL: *res = vm_from_f64((double)ia); return true;
+    case GMLRT_SOP_FLOOR: *res = (uint64_t)vm_floor_i64(fa); return true;
+    case GMLRT_SOP_ADDF: *res = vm_from_f64(fa + fb); return true;
+    case GMLRT_SOP_SUBF: *res = vm_from_f64(fa - fb); return true;
+    case GMLRT_SOP_MULF: *res = vm_from_f64(fa * fb); return true;
+    case GMLRT_SOP_DIVF: *res = vm_from_f64(fa / fb); return true;
+    case GMLRT_SOP_EQF: *res = fa == fb; return true;
+    case GMLRT_SOP_LESSF: *res = fa < fb; return true;
+    case GMLRT_SOP_SQRT: *res = vm_from_f64(sqrt(fa)); return true;
+    case GMLRT_SOP_FRAC: *res = vm_from_f64(vm_frac(fa)); return true;
+    case GMLRT_SOP_CLAMPF: *res = vm_from_f64(vm_clampf(fa)); return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_t>& out) {
+  const SurfInstr* prog = (const SurfInstr*)records;
+  const uint32_t imm[3] = {GMLRT_SI_IMM_A, GMLRT_SI_IMM_B, GMLRT_SI_IMM_C};
+  // forward: registers with a known value become immediates, operations on immediates fold
+  bool known[GMLRT_SURF_MAX_REGS] = {false};
+  uint64_t value[GMLRT_SURF_MAX_REGS] = {0};
+  known[0] = true;
+  value[0] = (uint64_t)face;
+  std::vector<SurfInstr> fwd;
+  for (size_t pc = 0;; pc++) {
+    SurfInstr I = prog[pc];
+    const uint32_t op = I.head & 0xFFu;
+    if (op == GMLRT_SOP_END) { fwd.push_back(I); break; }
+    bool reads[3];
+    surf_reads(op, reads);
+    uint64_t* slot[3] = {&I.a, &I.b, &I.c};
+    for (int k = 0; k < 3; k++) {
+      if (!reads[k]) { *slot[k] = 0; I.head |= imm[k]; continue; }  // an operand nobody looks at
+      if (!(I.head & imm[k]) && known[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)]) {
+        *slot[k] = value[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)];
+        I.head |= imm[k];
+      }
+    }
+    if (op == GMLRT_SOP_OUT) { fwd.push_back(I); continue; }
+    const uint32_t dst = (I.head >> 8) & (GMLRT_SURF_MAX_REGS - 1);
+    if (op == GMLRT_SOP_SELECT) {
+      const bool same = ((I.head & imm[1]) != 0) == ((I.head & imm[2]) != 0) && I.b == I.c;
+      if ((I.head & imm[0]) || same) {
+        // a move of the chosen side
+        const bool take_b = same || I.a != 0;
+        const uint64_t v = take_b ? I.b : I.c;
+        const bool v_imm = (I.head & (take_b ? imm[1] : imm[2])) != 0;
+        if (v_imm) { known[dst] = true; value[dst] = v; continue; }
+        if ((v & (GMLRT_SURF_MAX_REGS - 1)) == dst) continue;  // onto itself: the value is unknown as before
+        SurfInstr M;
+        std::memset(&M, 0, sizeof(M));
+        M.head = (uint32_t)GMLRT_SOP_MOV | (dst << 8) | imm[1] | imm[2];
+        M.a = v;
+        fwd.push_back(M);
+        known[dst] = false;
+        continue;
+      }
+    } else {
+      bool all_imm = true;
+      for (int k = 0; k < 3; k++) all_imm = all_imm && (I.head & imm[k]);
+      uint64_t res;
+      if (all_imm && surf_fold(op, I.a, I.b, &res)) { known[dst] = true; value[dst] = res; continue; }
+    }
+    known[dst] = false;
+    fwd.push_back(I);
+  }
+  // backward: drop what no OUT depends on
+  bool live[GMLRT_SURF_MAX_REGS] = {false};
+  std::vector<SurfInstr> kept;
+  for (size_t i = fwd.size(); i-- > 0;) {
+    const SurfInstr& I = fwd[i];
+    const uint32_t op = I.head & 0xFFu;
+    if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT) {
+      const uint32_t dst = (I.head >> 8) & (GMLRT_SURF_MAX_REGS - 1);
+      if (!live[dst]) continue;
+      live[dst] = false;
+    }
+    const uint64_t opnd[3] = {I.a, I.b, I.c};
+    for (int k = 0; k < 3; k++)
+      if (!(I.head & imm[k])) live[opnd[k] & (GMLRT_SURF_MAX_REGS - 1)] = true;
+    kept.push_back(I);
+  }
+  for (size_t i = kept.size(); i-- > 0;) {
+    const uint8_t* b = (const uint8_t*)&kept[i];
+    out.insert(out.end(), b, b + sizeof(SurfInstr));
+  }
+}
+
+void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+  if (p.constant) {
+    for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
+    return;
+  }
+  std::vector<uint8_t> rec, spec;
+  expand_surface(p.code.data(), p.consts.data(), rec);
+  specialize_surface(rec.data(), face, spec);
+  uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
+  surface_stream_vm<true>((const SurfInstr*)spec.data(), face, u, v, out, R);
+}
+
 // ============================================================== flattening
 namespace {
 

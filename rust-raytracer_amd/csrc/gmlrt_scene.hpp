@@ -41,6 +41,13 @@ void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v
 // surface's first constant.
 void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<uint8_t>& out);
 
+// The program `records` (SurfInstr records up to and including END) with `face` known:
+// constants propagated, operations on constants folded, dead code dropped.  Appends the
+// result (END included) to `out`.  What the device runs for a hit on that face.
+void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_t>& out);
+// Host run of the specialised program (unit tests: must equal run_surface_program bit for bit).
+void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+
 // Flattens one render call.  Throws UnsupportedSurface / gml::GmlError.
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc);
 

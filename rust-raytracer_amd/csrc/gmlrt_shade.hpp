@@ -73,7 +73,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       const gmlrt_leaf* L = leaves + (h_meta & kLeafMask);
       face = (int)((h_meta >> kFaceShift) & 7u);
       const uint32_t type = L->type;
-      mysurf = const_space(wave_uniform(SA->leaf_surf))[h_meta & kLeafMask];
+      mysurf = const_space(wave_uniform(SA->leaf_surf))[(h_meta & kLeafMask) * kSurfFaces + (uint32_t)face];
       double scale; V3 rd, rp;
       to_object(L->inv_m, S.o, S.d, scale, rd, rp);
       PrimHit ph = isect_prim(type, rp, rd);

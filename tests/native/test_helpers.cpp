@@ -167,6 +167,9 @@ int th_surface_compare(const char* path, int idx, int samples, unsigned seed, do
         double o2[6];
         gmlrt::run_surface_words(it->second, face, uu, vv, o2);  // both interpreters must agree bit for bit
         if (std::memcmp(o, o2, sizeof(o)) != 0) stats[2] = INFINITY;
+        double o3[6];
+        gmlrt::run_surface_specialized(it->second, face, uu, vv, o3);  // and so must the program specialised for the face
+        if (std::memcmp(o, o3, sizeof(o)) != 0) stats[2] = INFINITY;
         const double ref[6] = {col[0], col[1], col[2], kd, ks, n};
         for (int k = 0; k < 6; k++) {
           stats[0] += 1;
@@ -202,6 +205,8 @@ int th_surface_eval_text(const char* text, const char* var, long long face, doub
     double got2[6];
     gmlrt::run_surface_words(sp, face, u, v, got2);
     if (std::memcmp(got, got2, sizeof(got2)) != 0) { put("the two bytecode interpreters disagree", err, errlen); return -1; }
+    gmlrt::run_surface_specialized(sp, face, u, v, got2);
+    if (std::memcmp(got, got2, sizeof(got2)) != 0) { put("the program specialised for the face disagrees", err, errlen); return -1; }
     return 0;
   } catch (gmlrt::UnsupportedSurface& e) {
     put(std::string("UNSUPPORTED ") + e.what(), err, errlen);
