@@ -18,8 +18,14 @@
 #ifndef GMLRT_TRAVERSE_INLINE
 #define GMLRT_TRAVERSE_INLINE inline
 #endif
+// Per-lane flags of the traversal, kept as bits of one integer register.  (As separate
+// booleans they are wave masks in scalar register pairs, and every join of control flow
+// in the loop below merges each of them with three scalar instructions.)  "A candidate has
+// been found" is bit 31 of best_m, the bit the caller's interface uses for it anyway.
+constexpr uint32_t kFlActive = 1u, kFlRedo = 2u;
+
 __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
-                                      uint32_t n_leaves, bool active, V3 o, V3 d, const double t_stop,
+                                      uint32_t n_leaves, bool active_in, V3 o, V3 d, const double t_stop,
                                       double* __restrict__ evD, uint32_t* __restrict__ evM,
                                       uint16_t* __restrict__ lens, Diag& dg) {
   Hit h = {false, 0.0, 0u, false};
@@ -28,26 +34,23 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     double scale; V3 rd, rp;
     to_object(leaves->inv_m, o, d, scale, rd, rp);
     PrimHit ph = isect_prim(leaves->type, rp, rd);
-    if (active && ph.bits) {
+    if (active_in && ph.bits) {
       h.any = true;
       if (ph.bits & 1) { h.dist = scale * ph.tA; h.meta = ((uint32_t)ph.fA << kFaceShift); }
       else { h.dist = scale * ph.tB; h.meta = ((uint32_t)ph.fB << kFaceShift) | kOrigExit | kCurExit; }
     }
     return h;
   }
-  bool found = false, redo = false;
+  uint32_t fl = active_in ? kFlActive : 0u;
   double best = 0.0;
-  uint32_t best_m = 0u;
-  uint32_t sp = 0;     // events on this lane's stack
-  uint32_t level = 0;  // operand stack depth (wave-uniform)
+  uint32_t best_m = 0u;  // bit 31 (kHitAny): a candidate has been found
+  uint32_t sp = 0;       // events on this lane's stack
+  uint32_t level = 0;    // operand stack depth (wave-uniform)
   const int tid = threadIdx.x;
-  uint32_t pc = 0;     // byte offset of the current record (wave-uniform)
+  uint32_t pc = 0;       // byte offset of the current record (wave-uniform)
   // for the box tests; a zero component gives +-inf, which the slab arithmetic below handles
   const V3 inv_d = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
   for (;;) {
-#if GMLRT_TOP_EXIT
-    if (!__ballot(active)) break;  // every lane has what it came for
-#endif
     // The first 64 bytes of the record, whatever its kind, in one scalar load: fetching the
     // kind first and the operands after the branch on it would be two dependent round trips
     // per record.  (The program is padded so that this never reads past its buffer.)
@@ -56,63 +59,54 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
 #define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
     const uint32_t kf = R[0];
     const uint32_t kind = kf & 0xFu;
-    if (kind == kRecBound) {
-      // Bounding sphere in front of a subtree: if no lane's ray comes near it, every
-      // list below is empty.  Under the union frontier that means "nothing to take";
-      // inside a frontier child the subtree's (empty) list is pushed.
-      // ProgBound: skip_to, center[3], radius2, radius
-      // The test only has to be conservative, not reproducible, so it uses fused
-      // multiply-adds and |perp|^2 = |oc|^2 - tca^2 (d has unit length); the slack added to
-      // r^2 covers the cancellation in that difference.  Any NaN compares false and keeps
+    if (kind == kRecBox || kind == kRecBound) {
+      // A bound in front of a subtree: if no lane's ray comes near it, every list below is
+      // empty.  Under the union frontier that means "nothing to take"; inside a frontier
+      // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
+      // not reproducible, so they use fused multiply-adds.  Any NaN compares false and keeps
       // the subtree.
-      const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
-      const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
-      const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
-      const double r2 = REC_F64(3);
-      const bool miss = !active || __builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2) || (tca < 0.0 && oc2 > r2)
+      bool hit;
+      uint32_t next;
+      if (kind == kRecBox) {
+        // ProgBox: skip_to, lo[3], hi[3].  Slab test; fmin/fmax return the other operand when
+        // one is NaN (0 * inf: the ray runs inside a face plane), which leaves that slab out.
+        const double x1 = (REC_F64(0) - o.x) * inv_d.x, x2 = (REC_F64(3) - o.x) * inv_d.x;
+        const double y1 = (REC_F64(1) - o.y) * inv_d.y, y2 = (REC_F64(4) - o.y) * inv_d.y;
+        const double z1 = (REC_F64(2) - o.z) * inv_d.z, z2 = (REC_F64(5) - o.z) * inv_d.z;
+        const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
+        const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+        // the relative slack covers the rounding of the six products
+        hit = (fl & kFlActive) && !(tfar * (1.0 + 1e-9) < tnear)
 #if GMLRT_TMAX_CULL
-                        || (found && tca - REC_F64(4) > best)
+              && !((best_m & kHitAny) && tnear > best)
 #endif
-          ;
-      DIAG(dg.n_bound++;)
-      if (!__ballot(!miss)) {
-        DIAG(dg.n_skip++;)
-        if (!(kf & kRecFlag)) {
-          lens[level * kBlock + tid] = 0;
-          level++;
-        }
-        pc = R[1];
+            ;
+        next = pc + (uint32_t)sizeof(ProgBox);
       } else {
-        pc += (uint32_t)sizeof(ProgBound);
-      }
-    } else if (kind == kRecBox) {
-      // The same for the subtree's axis-aligned box: slab test.  fmin/fmax return the
-      // other operand when one is NaN (0 * inf: the ray runs inside a face plane), which
-      // leaves that slab out; a NaN direction keeps the subtree.
-      // ProgBox: skip_to, lo[3], hi[3]
-      const double x1 = (REC_F64(0) - o.x) * inv_d.x, x2 = (REC_F64(3) - o.x) * inv_d.x;
-      const double y1 = (REC_F64(1) - o.y) * inv_d.y, y2 = (REC_F64(4) - o.y) * inv_d.y;
-      const double z1 = (REC_F64(2) - o.z) * inv_d.z, z2 = (REC_F64(5) - o.z) * inv_d.z;
-      const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
-      const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-      // the relative slack covers the rounding of the six products
-      const bool miss = !active || tfar * (1.0 + 1e-9) < tnear
+        // ProgBound: skip_to, center[3], radius2, radius.  |perp|^2 = |oc|^2 - tca^2 (d has
+        // unit length); the slack added to r^2 covers the cancellation in that difference.
+        const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
+        const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
+        const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
+        const double r2 = REC_F64(3);
+        hit = (fl & kFlActive) && !(__builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2)) && !(tca < 0.0 && oc2 > r2)
 #if GMLRT_TMAX_CULL
-                        || (found && tnear > best)
+              && !((best_m & kHitAny) && tca - REC_F64(4) > best)
 #endif
-          ;
-      DIAG(dg.n_bound++;)
-      if (!__ballot(!miss)) {
-        DIAG(dg.n_skip++;)
-        if (!(kf & kRecFlag)) {
-          lens[level * kBlock + tid] = 0;
-          level++;
-        }
-        pc = R[1];
-      } else {
-        pc += (uint32_t)sizeof(ProgBox);
+            ;
+        next = pc + (uint32_t)sizeof(ProgBound);
       }
-    } else if (kind == kRecLeaf) {
+      DIAG(dg.n_bound++;)
+      if (__ballot(hit)) { pc = next; continue; }
+      DIAG(dg.n_skip++;)
+      if (!(kf & kRecFlag)) {
+        lens[level * kBlock + tid] = 0;
+        level++;
+      }
+      pc = R[1];
+      continue;
+    }
+    if (kind == kRecLeaf) {
       // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
       const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
       const double im[12] = {REC_F64(0), REC_F64(1), REC_F64(2), REC_F64(3), REC_F64(4), REC_F64(5), REC_F64(6),
@@ -122,40 +116,42 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       PrimHit ph = isect_prim((kf >> 16) & 7u, rp, rd);
       const uint32_t leaf = R[1];
       DIAG(dg.n_leaf++;)
+      pc += (uint32_t)sizeof(ProgLeaf);
       // a list that starts with Exit never raises its operand's counter above zero
       // (primitives.rs:254-293 start both counters at 0): same as no list at all
-      const bool entry = active && (ph.bits & 1);
+      const bool entry = (fl & kFlActive) && (ph.bits & 1);
       const double d0 = scale * ph.tA, d1 = scale * ph.tB;
       const bool sliver = (ph.bits & 2) && (d1 - d0 < 1e-10);
       if (kf & kRecFlag) {
         // frontier leaf: no list, just a candidate for the nearest first Entry
         if (entry) {
-          if (sliver) redo = true;
-          else if (!found || d0 < best || (d0 == best && leaf < (best_m & kLeafMask))) {
-            found = true; best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift);
+          if (sliver) fl |= kFlRedo;
+          else if (!(best_m & kHitAny) || d0 < best || (d0 == best && leaf < (best_m & kLeafMask))) {
+            best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift) | kHitAny;
           }
 #if GMLRT_TSTOP
-          if (found && best <= t_stop) active = false;
+          if ((best_m & kHitAny) && best <= t_stop) fl &= ~kFlActive;
 #endif
         }
-      } else {
-        uint32_t n = 0;
-        if (entry) {
-          evD[(size_t)sp * kWave] = d0;
-          evM[(size_t)sp * kWave] = leaf | ((uint32_t)ph.fA << kFaceShift);
-          n = 1;
-          if (ph.bits & 2) {
-            evD[(size_t)(sp + 1) * kWave] = d1;
-            evM[(size_t)(sp + 1) * kWave] = leaf | ((uint32_t)ph.fB << kFaceShift) | kOrigExit | kCurExit;
-            n = sliver ? (2u | 0x8000u) : 2u;
-          }
-        }
-        lens[level * kBlock + tid] = (uint16_t)n;
-        sp += n & 0x7FFFu;
-        level++;
+        continue;
       }
-      pc += (uint32_t)sizeof(ProgLeaf);
-    } else if (kind == kRecOp) {
+      uint32_t n = 0;
+      if (entry) {
+        evD[(size_t)sp * kWave] = d0;
+        evM[(size_t)sp * kWave] = leaf | ((uint32_t)ph.fA << kFaceShift);
+        n = 1;
+        if (ph.bits & 2) {
+          evD[(size_t)(sp + 1) * kWave] = d1;
+          evM[(size_t)(sp + 1) * kWave] = leaf | ((uint32_t)ph.fB << kFaceShift) | kOrigExit | kCurExit;
+          n = sliver ? (2u | 0x8000u) : 2u;
+        }
+      }
+      lens[level * kBlock + tid] = (uint16_t)n;
+      sp += n & 0x7FFFu;
+      level++;
+      continue;
+    }
+    if (kind == kRecOp) {
       const uint32_t rule = R[1] & 3u;
       const uint32_t lenB = lens[(level - 1) * kBlock + tid], lenA = lens[(level - 2) * kBlock + tid];
       const uint32_t lb = lenB & 0x7FFFu, la = lenA & 0x7FFFu;
@@ -181,30 +177,34 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       sp = a0 + lout;
       level--;
       pc += (uint32_t)sizeof(ProgSmall);
-    } else if (kind == kRecTake) {
+      continue;
+    }
+    if (kind == kRecTake) {
       // a frontier child is complete: its list is the only one on the stack and, being an
       // operator's output, starts with an Entry and holds no sliver
       const uint32_t n = lens[tid] & 0x7FFFu;
       DIAG(dg.n_take++;)
-      if (active && n) {
+      if ((fl & kFlActive) && n) {
         const double d0 = evD[0];
         const uint32_t m0 = evM[0];
-        if (!found || d0 < best || (d0 == best && (m0 & kLeafMask) < (best_m & kLeafMask))) { found = true; best = d0; best_m = m0; }
+        if (!(best_m & kHitAny) || d0 < best || (d0 == best && (m0 & kLeafMask) < (best_m & kLeafMask))) {
+          best = d0; best_m = m0 | kHitAny;
+        }
 #if GMLRT_TSTOP
-        if (best <= t_stop) active = false;
+        if (best <= t_stop) fl &= ~kFlActive;
 #endif
       }
       sp = 0;
       level = 0;
       pc += (uint32_t)sizeof(ProgSmall);
-    } else {
-      break;  // kRecEnd
+      continue;
     }
+    break;  // kRecEnd
   }
 #undef REC_F64
-  h.any = found;
+  h.any = (best_m & kHitAny) != 0;
   h.dist = best;
-  h.meta = best_m;
-  h.redo = redo;
+  h.meta = best_m & ~kHitAny;
+  h.redo = (fl & kFlRedo) != 0;
   return h;
 }
