@@ -59,6 +59,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
 #define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
     const uint32_t kf = R[0];
     const uint32_t kind = kf & 0xFu;
+    level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);  // wave-uniform by construction: say so
     if (kind == kRecBox || kind == kRecBound) {
       // A bound in front of a subtree: if no lane's ray comes near it, every list below is
       // empty.  Under the union frontier that means "nothing to take"; inside a frontier
