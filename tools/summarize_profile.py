@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the files kept under
+profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <name>_pmc_summary.json (counter means per
+render_kernel launch + derived figures), <name>_bench.json and <name>_bench_under_rocprof.json.
+Usage: tools/summarize_profile.py <tag> <name>     e.g.  tools/summarize_profile.py r01b r01_final"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+assert stats, "no kernel stats under " + src
+shutil.copy(stats[0], os.path.join(dst, name + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, name + "_bench.json"))
+shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, name + "_bench_under_rocprof.json"))
+
+tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "render_kernel" not in r["Kernel_Name"]:
+            continue
+        tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[r["Counter_Name"]] += 1
+c = {k: round(tot[k] / cnt[k], 1) for k in sorted(tot)}
+launches = max(cnt.values())
+cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+derived = {
+    "gpu_cycles_per_launch": round(cycles),
+    "valu_busy_fraction": round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), 3),
+    "valu_busy_fraction_note": "SQ_INSTS_VALU x 4 cycles (a wave64 instruction occupies a 16-lane SIMD for 4 cycles) / (1024 SIMDs x cycles)",
+    "salu_per_valu": round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 2),
+    "fetch_bytes_per_launch": round(c["FETCH_SIZE"] * 1024),
+    "write_bytes_per_launch": round(c["WRITE_SIZE"] * 1024),
+    "traffic_note": "FETCH_SIZE/WRITE_SIZE are in KiB per dispatch (checked against a 24.9 MB fill kernel: WRITE_SIZE 24300). They count L2<->fabric requests, Infinity Cache hits included. The reads here are 8 B/lane, a width the guide calls uncalibrated; no doubling applied.",
+}
+json.dump({
+    "command": "rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)",
+    "workload": "chess.gml 3840x2160 depth 5, 1 MI355X, per render_kernel launch (mean of %d launches)" % launches,
+    "counters": c, "derived": derived}, open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(derived, indent=1))
