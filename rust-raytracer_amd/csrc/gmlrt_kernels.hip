@@ -112,7 +112,8 @@ struct ShadeArgs {
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
 // where the cycles went.  Never part of the shipped library; numbers from it are
 // shares, not timings.
-struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes, n_redo; };
+struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes, n_redo,
+              b_lanes, l_lanes, l_hits, k_trav[3], k_leaf[3]; };
 #ifdef GMLRT_DIAG
 #define DIAG(...) __VA_ARGS__
 #else
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   uint32_t cur_tile = 0xFFFFFFFFu;
   unsigned long long tile_t0 = 0;
   DIAG(unsigned long long dbg_trav0 = 0, dbg_leaf0 = 0, dbg_merge0 = 0, dbg_redo0 = 0;)
-  Diag dg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Diag dg = {};
   DIAG(unsigned long long t0 = __builtin_readcyclecounter(); const unsigned long long w_start = wall_clock64();
        unsigned long long w_tiles = 0;)
 
@@ -562,6 +563,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
          dg.lanes += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
 
+    DIAG(const unsigned long long dk_leaf0 = dg.n_leaf;
+         // what the wave is tracing: 0 camera rays only, 1 shadow rays of camera hits among them, 2 anything after a bounce
+         const int dk = __ballot(st_kind(S.st) != kIdle && ((S.st >> 2) & 0x7FFu) != 0) ? 2 : __ballot(st_kind(S.st) == kShadow) ? 1 : 0;)
     // ---- one scene traversal for whatever ray each lane holds
     Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if (__ballot(h.redo)) {
@@ -572,7 +576,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       if (h.redo) h = g;
     }
     // ---- then the per-ray bookkeeping, out of line
-    DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;)
+    DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;
+         dg.k_trav[dk]++; dg.k_leaf[dk] += dg.n_leaf - dk_leaf0;)
     if (st_kind(S.st) != kIdle) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
       uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
@@ -603,7 +608,11 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(atomicAdd(&A.diag[0], dg.t_refill); atomicAdd(&A.diag[1], dg.t_trav); atomicAdd(&A.diag[2], dg.t_after);
          atomicAdd(&A.diag[3], dg.n_trav); atomicAdd(&A.diag[4], dg.n_bound); atomicAdd(&A.diag[5], dg.n_skip);
          atomicAdd(&A.diag[6], dg.n_leaf); atomicAdd(&A.diag[7], dg.n_merge); atomicAdd(&A.diag[8], dg.n_take);
-         atomicAdd(&A.diag[9], dg.lanes);)
+         atomicAdd(&A.diag[9], dg.lanes); atomicAdd(&A.diag[16], dg.b_lanes); atomicAdd(&A.diag[17], dg.l_lanes);
+         atomicAdd(&A.diag[18], dg.l_hits);
+         for (int q = 0; q < 3; q++) atomicAdd(&A.diag[19 + q], dg.k_trav[q]);
+         for (int q = 0; q < 2; q++) atomicAdd(&A.diag[22 + q], dg.k_leaf[q]);  // the third is the rest of n_leaf; the table ends at slot 23
+         )
   }
 }
 
@@ -1047,6 +1056,18 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       std::fprintf(stderr, "[gmlrt diag] surface program runs %llu (%.2f per traversal), lanes wanting one %.1f per traversal\n",
                    vm_runs, (double)vm_runs / ((double)dgv[3] > 0 ? (double)dgv[3] : 1.0),
                    (double)vm_lanes / ((double)dgv[3] > 0 ? (double)dgv[3] : 1.0));
+    }
+    {
+      unsigned long long ex[9];
+      HIP_TRY(hipMemcpy(ex, (uint8_t*)s->d_counters + 64 + 16 * 8, 8 * sizeof(ex[0]), hipMemcpyDeviceToHost));
+      ex[8] = dgv[6] - ex[6] - ex[7];
+      const double entered = (double)(dgv[4] - dgv[5]) > 0 ? (double)(dgv[4] - dgv[5]) : 1.0, nl = (double)dgv[6] > 0 ? (double)dgv[6] : 1.0;
+      std::fprintf(stderr, "[gmlrt diag] lanes whose ray meets an entered bound %.1f; per leaf test: lanes taking part %.1f, with an Entry %.1f\n",
+                   (double)ex[0] / entered, (double)ex[1] / nl, (double)ex[2] / nl);
+      const char* names[3] = {"camera", "shadow of camera hits", "after a bounce"};
+      for (int q = 0; q < 3; q++)
+        std::fprintf(stderr, "[gmlrt diag] waves tracing %-22s: %llu traversals, %.1f leaves each\n", names[q], ex[3 + q],
+                     (double)ex[6 + q] / ((double)ex[3 + q] > 0 ? (double)ex[3 + q] : 1.0));
     }
     const double nt = (double)dgv[3] > 0 ? (double)dgv[3] : 1.0;
     std::fprintf(stderr,

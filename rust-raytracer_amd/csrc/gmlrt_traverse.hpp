@@ -98,6 +98,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
         next = pc + (uint32_t)sizeof(ProgBound);
       }
       DIAG(dg.n_bound++;)
+      DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
       if (__ballot(hit)) { pc = next; continue; }
       DIAG(dg.n_skip++;)
       if (!(kf & kRecFlag)) {
@@ -123,6 +124,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       const bool entry = (fl & kFlActive) && (ph.bits & 1);
       const double d0 = scale * ph.tA, d1 = scale * ph.tB;
       const bool sliver = (ph.bits & 2) && (d1 - d0 < 1e-10);
+      DIAG(dg.l_lanes += (unsigned long long)__popcll(__ballot((fl & kFlActive) != 0)); dg.l_hits += (unsigned long long)__popcll(__ballot(entry));)
       if (kf & kRecFlag) {
         // frontier leaf: no list, just a candidate for the nearest first Entry
         if (entry) {
