@@ -186,6 +186,46 @@ def test_bound_volumes_do_not_change_results(gmlrt, oracle, label, scene, size):
     assert st.rays_shadow > 0 and st.rays_reflect > 0
 
 
+def _rare_path_scenes():
+    # (a) an operand stack 12 deep: twelve spheres intersected right to left (postfix: twelve leaves, then eleven
+    #     operators); the stack lengths then leave no room in LDS for the shading context, which selects the
+    #     kernel that keeps it in device memory
+    deep = " ".join("m sphere 2.0 uscale %.2f %.2f 4.0 translate" % (0.07 * i - 0.4, 0.05 * (i % 3) - 0.05) for i in range(12))
+    deep += " intersect" * 11 + " m plane 0.0 -1.2 0.0 translate union"
+    # (b) lists longer than the in-register merge handles: seven disjoint spheres in a row along the view axis,
+    #     united inside an intersection (so the unions are evaluated with full lists: up to 14 events)
+    row = " ".join("m sphere 0.3 uscale 0.0 0.0 %.1f translate" % (2.0 + 0.8 * i) for i in range(7)) + " union" * 6
+    long_lists = row + " m cube 4.0 4.0 8.0 scale -2.0 -2.0 1.5 translate intersect m plane 0.0 -1.0 0.0 translate union"
+    return [("deep_operand_stack", SURF, deep), ("long_lists", SURF, long_lists)]
+
+
+def _many_register_surface():
+    # (c) a surface function that keeps 24 values alive until the end: more registers than the interpreter holds in LDS
+    terms = " ".join("u %d.0 mulf v %d.5 mulf addf frac /t%d" % (i + 1, i, i) for i in range(24))
+    # summed twice, front to back and back to front: every term is live from the first sum to the second
+    total = "t0 " + " ".join("t%d addf" % i for i in range(1, 24))
+    back = "t23 " + " ".join("t%d addf" % i for i in range(22, -1, -1))
+    surf = "{ /v /u /face %s %s 24.0 divf /s %s 24.0 divf /r s 1.0 r subf 0.5 point 0.8 0.3 4.0 } /m " % (terms, total, back)
+    scene = ("m sphere 0.0 0.0 3.0 translate m cube -2.5 -1.0 3.0 translate union m cylinder 1.5 -1.0 3.0 translate union "
+             "m plane 0.0 -1.0 0.0 translate union")
+    return [("many_registers", surf, scene)]
+
+
+@pytest.mark.parametrize("label,surf,scene", _rare_path_scenes() + _many_register_surface())
+def test_rarely_taken_paths(gmlrt, oracle, label, surf, scene):
+    text = surf + LIGHT + scene + ' /s 0.3 0.3 0.3 point [ l ] s 3 90.0 160 120 "x.ppm" render'
+    call = gmlrt.Program(text=text).calls[0]
+    hdr = np.frombuffer(call.blob, dtype=np.uint32, count=12)
+    img, f64, st = gmlrt.render(call, want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print(label, "differing=%d max=%d" % (ndiff, maxd), st.as_dict(), "header", hdr.tolist())
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert np.abs(f64 - ref64).max() <= 1e-9
+    assert st.rays_shadow > 0 and st.rays_reflect > 0 and len(np.unique(img)) > 8
+
+
 # The reference's other scene files (its gml/ directory): every `render` each program executes, at the
 # size and depth the file names.  They exercise what the seven configuration scenes do not: array `get`
 # inside surface functions (checked-cube, cube), closures as values (holes), clampf/frac (golf), several
