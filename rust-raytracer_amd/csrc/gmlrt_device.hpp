@@ -74,6 +74,8 @@ struct DeviceScene {
   // hand-out order of the pixel tiles, learnt from the first launch with a given geometry
   void* d_tile_cost = nullptr;  // u32 per tile, written by every launch
   void* d_tile_order = nullptr; // u32 per tile: tiles sorted by decreasing cost
+  void* d_tile_batch = nullptr; // u32 per batch + 1: first hand-out of each batch of that order
+  uint32_t n_batches = 0;
   size_t tiles_alloc = 0;
   bool order_valid = false;     // d_tile_order holds an order for order_key
   bool learn_order = true;      // false for a handle that renders once: learning would never pay
