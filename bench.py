@@ -128,9 +128,9 @@ def main():
             rowtiles.gather_to_rank0(out, gathered)  # the final framebuffer gather: the only collective
         return st
 
-    # Scene preparation, like the upload above: the library learns the hand-out order of the pixel tiles
-    # from the first launch with a given geometry and tries it in the second (gmlrt_kernels.hip).
-    for _ in range(2):
+    # Scene preparation, like the upload above: the library times the pixel tiles in the first launch with a
+    # given geometry and tries two other ways of handing them out in the second and third (gmlrt_kernels.hip).
+    for _ in range(3):
         scene.render_into(p, out.data_ptr(), None, stream)
     for _ in range(args.warmup):
         step()

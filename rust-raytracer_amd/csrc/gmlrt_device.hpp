@@ -79,9 +79,14 @@ struct DeviceScene {
   size_t tiles_alloc = 0;
   bool order_valid = false;     // d_tile_order holds an order for order_key
   bool learn_order = true;      // false for a handle that renders once: learning would never pay
-  int order_state = 0;          // 0: nothing learnt, 1: order built, on trial in the next launch, 2: decided
-  bool order_use = false;       // the trial launch was faster than the one in image order
-  float order_base_ms = 0.f;    // kernel time of the launch in image order
+  // Three ways of handing out the tiles: 0 image order, fixed small batches; 1 the learnt order with its batch
+  // table; 2 image order with a batch table of its own.  order_state counts the launches with this geometry:
+  // 0 nothing learnt (runs way 0 and times its tiles), 1 and 2: ways 1 and 2 on trial, 3: decided (order_way).
+  int order_state = 0;
+  int order_way = 0;            // the fastest of the three (a trial has to beat way 0 by 2 %)
+  float order_ms[3] = {0.f, 0.f, 0.f};  // kernel time of the launch that ran each way
+  void* d_tile_batch_img = nullptr;      // way 2's batch table
+  uint32_t n_batches_img = 0;
   gmlrt_params order_key{};     // the launch parameters the order belongs to (ambient zeroed)
   void* ev_start = nullptr;     // hipEvent_t pair used to time the kernel
   void* ev_stop = nullptr;

@@ -708,6 +708,7 @@ void free_workspace(DeviceScene* s) {
   (void)hipFree(s->d_tile_cost);
   (void)hipFree(s->d_tile_order);
   (void)hipFree(s->d_tile_batch);
+  (void)hipFree(s->d_tile_batch_img);
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
 }
@@ -786,7 +787,7 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.d_ev_dist = s->d_ev_dist; spare.d_ev_meta = s->d_ev_meta; spare.d_ctx = s->d_ctx;
   spare.d_counters = s->d_counters;
   spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc; spare.lanes_alloc = s->lanes_alloc;
-  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.tiles_alloc = s->tiles_alloc;
+  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
   {
@@ -930,10 +931,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     (void)hipFree(s->d_tile_order);
     s->d_tile_cost = s->d_tile_order = nullptr;
     (void)hipFree(s->d_tile_batch);
-    s->d_tile_batch = nullptr;
+    (void)hipFree(s->d_tile_batch_img);
+    s->d_tile_batch = s->d_tile_batch_img = nullptr;
     HIP_TRY(hipMalloc(&s->d_tile_cost, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_order, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch, (n_tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_tile_batch_img, (n_tiles + 1) * sizeof(uint32_t)));
     s->tiles_alloc = n_tiles;
     s->order_valid = false;
   }
@@ -943,11 +946,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (s->order_valid && std::memcmp(&key, &s->order_key, sizeof(key)) != 0) s->order_valid = false;
   if (!s->order_valid) s->order_state = 0;
   static const bool no_order = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
-  const bool ordered = s->order_valid && !no_order && (s->order_state == 1 || (s->order_state == 2 && s->order_use));
+  const int way = !s->order_valid || no_order ? 0 : s->order_state == 1 ? 1 : s->order_state == 2 ? 2 : s->order_state == 3 ? s->order_way : 0;
+  const bool ordered = way == 1;
   A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
-  A.batch_start = ordered ? (const uint32_t*)s->d_tile_batch : nullptr;
+  A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img : nullptr;
   A.n_tiles = (uint32_t)n_tiles;
-  A.n_batches = ordered ? s->n_batches : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
   A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
 #ifdef GMLRT_DIAG
   unsigned long long* d_tile_dbg = nullptr;
@@ -997,11 +1001,19 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
-  if (s->order_state == 1 && ordered) {
-    // the trial: keep the order only if it paid (it trades cache locality between neighbouring waves
-    // for a shorter tail; scenes with evenly priced tiles lose)
-    s->order_use = ms < 0.98f * s->order_base_ms;
-    s->order_state = 2;
+  if ((s->order_state == 1 || s->order_state == 2) && way == s->order_state) {
+    // a trial: the learnt order trades cache locality between neighbouring waves for a shorter tail (scenes
+    // with evenly priced tiles lose); the batch table over the image order only saves atomics
+    s->order_ms[way] = ms;
+    if (++s->order_state == 3) {
+      s->order_way = 0;
+      float best = 0.98f * s->order_ms[0];
+      for (int k = 1; k <= 2; k++)
+        if (s->order_ms[k] < best) { best = s->order_ms[k]; s->order_way = k; }
+      if (std::getenv("GMLRT_VERBOSE"))
+        std::fprintf(stderr, "[gmlrt] tile hand-out: image order %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms -> way %d\n",
+                     s->order_ms[0], s->order_ms[1], s->order_ms[2], s->order_way);
+    }
   } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
     // first launch with this geometry: turn its per-tile costs into the order of the next ones
     // (worth it only when a wave renders several tiles)
@@ -1055,31 +1067,41 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       unsigned long long total = 0;
       for (uint32_t c : ticks) total += c;
       const unsigned long long waves = (unsigned long long)grid * (kBlock / kWave);
-      const unsigned long long target = total / (waves * 24ull) + 1ull;
-      std::vector<uint32_t> start;
-      start.reserve(n_tiles + 1);
-      unsigned long long acc = 0;
-      uint32_t in_batch = 0;
-      for (size_t i = 0; i < n_tiles; i++) {
-        const unsigned long long c = ticks[order[i]];
-        if (in_batch == 0 || in_batch >= kTileBatchMax || acc + c > target) {
-          start.push_back((uint32_t)i);
-          acc = 0;
-          in_batch = 0;
+      // Two limits on the number of batches: enough of them that the last ones even out the end of the
+      // launch (two dozen a wave), and few enough that the claims, which the memory system serves one at
+      // a time (about 14 ns each), stay a small part of the launch: at most one claim per 56 ns of it.
+      unsigned long long n_target = waves * 24ull;
+      const unsigned long long by_claims = (unsigned long long)((double)ms * 1e6 / 56.0) + 1ull;
+      if (n_target > by_claims) n_target = by_claims;
+      const unsigned long long target = total / n_target + 1ull;
+      auto build = [&](bool in_learnt_order, void* d_table, uint32_t* n_out) -> hipError_t {
+        std::vector<uint32_t> start;
+        start.reserve(n_tiles + 1);
+        unsigned long long acc = 0;
+        uint32_t in_batch = 0;
+        for (size_t i = 0; i < n_tiles; i++) {
+          const unsigned long long c = ticks[in_learnt_order ? order[i] : i];
+          if (in_batch == 0 || in_batch >= kTileBatchMax || acc + c > target) {
+            start.push_back((uint32_t)i);
+            acc = 0;
+            in_batch = 0;
+          }
+          acc += c;
+          in_batch++;
         }
-        acc += c;
-        in_batch++;
-      }
-      s->n_batches = (uint32_t)start.size();
-      start.push_back((uint32_t)n_tiles);
-      HIP_TRY(hipMemcpy(s->d_tile_batch, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        *n_out = (uint32_t)start.size();
+        start.push_back((uint32_t)n_tiles);
+        return hipMemcpy(d_table, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      };
+      HIP_TRY(build(true, s->d_tile_batch, &s->n_batches));
+      HIP_TRY(build(false, s->d_tile_batch_img, &s->n_batches_img));
       if (std::getenv("GMLRT_VERBOSE"))
-        std::fprintf(stderr, "[gmlrt] %zu tiles in %u batches\n", n_tiles, s->n_batches);
+        std::fprintf(stderr, "[gmlrt] %zu tiles in %u batches (learnt order), %u batches (image order)\n", n_tiles, s->n_batches, s->n_batches_img);
     }
     s->order_key = key;
     s->order_valid = true;
     s->order_state = 1;
-    s->order_base_ms = ms;
+    s->order_ms[0] = ms;
   }
 #ifdef GMLRT_DIAG
   {
