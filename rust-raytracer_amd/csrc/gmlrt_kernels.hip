@@ -46,6 +46,14 @@ constexpr int kCtxFixed = 24;             // f64 fields of the shading context b
 constexpr int kCtxPerLevel = 7;
 constexpr uint32_t kTileBatch = 4;      // tiles per claim when no batch table is given
 constexpr uint32_t kTileBatchMax = 16;  // most tiles a batch of the table holds
+// Atomics on one address are served one after the other, device-wide (about 14 ns each, measured): the
+// batch counter is therefore split into several, far enough apart to be different memory channels.
+constexpr uint32_t kClaimCounters = 8, kClaimStride = 4096;
+// Layout of the per-scene counter buffer: the claim counters, 256 bytes of diagnostic counters, the ShadeArgs
+// record, one set of ray counts per block.
+constexpr size_t kOffDiag = (size_t)kClaimCounters * kClaimStride, kOffShadeArgs = kOffDiag + 256, kOffBlockCounts = kOffDiag + 1024;
+constexpr size_t kMaxGridBlocks = 8192;
+constexpr size_t kCountersBytes = kOffBlockCounts + kMaxGridBlocks * 4 * sizeof(unsigned long long);
 [[maybe_unused]] constexpr int kDiagWaveSlots = 12;  // diagnostic build: counters per wave
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
@@ -87,8 +95,8 @@ struct KArgs {
   uint32_t n_tiles;
   unsigned long long* tile_dbg;  // diagnostic build only: per tile, 4 counters
   uint32_t* tile_cost;         // per tile: how long its wave spent on it (wall-clock ticks); null: not wanted
-  unsigned int* next_slot;
-  unsigned long long* ray_counts;  // primary, shadow, reflect, shaded hits
+  unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
+  unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
 };
 
@@ -113,6 +121,8 @@ struct ShadeArgs {
   const SurfInstr* surf_prog;  // expanded surface programs
   unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
 };
+
+static_assert(sizeof(ShadeArgs) <= kOffBlockCounts - kOffShadeArgs, "ShadeArgs outgrew its slot in the counter buffer");
 
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
 // where the cycles went.  Never part of the shipped library; numbers from it are
@@ -501,6 +511,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   uint32_t tile_base = 0;  // next slot of the wave's tile
   uint32_t tile_left = 0;  // slots of it not handed out yet
   uint32_t batch_pos = 0, batch_end = 0;  // hand-outs claimed from the global counter and not started yet
+  uint32_t claim_g = blockIdx.x % kClaimCounters, claim_tries = 0;  // counter in use, counters found empty
   // Tiles differ a lot in cost (sky: one traversal; a piece between mirrors: a dozen heavy ones) and
   // a wave follows its tile through every bounce, so the launch ends when the last expensive tile
   // does.  Each wave therefore notes how long its tiles took; the host sorts that into the hand-out
@@ -523,10 +534,20 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           // device add to the same address, which the memory system serves one after the other
           // (about 14 ns each, measured); per tile that alone took 1.8 ms of a 4K frame, the
           // whole frame time of a simple scene.
-          uint32_t b = 0;
-          if (lane == 0) b = atomicAdd(A.next_slot, 1u);
-          b = (uint32_t)__shfl((int)b, 0);
-          b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+          // counter g hands out batches g, g + 8, g + 16, ...; a wave starts with the counter of its block
+          // (blocks go to the chip's eight dies in turn, so a die mostly keeps to one counter) and moves
+          // on to the next when one has run out; all eight empty: nothing left
+          uint32_t b = A.n_batches;
+          while (claim_tries < kClaimCounters) {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd((unsigned int*)((uint8_t*)A.next_batch + (size_t)claim_g * kClaimStride), 1u);
+            k = (uint32_t)__shfl((int)k, 0);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const uint64_t cand = (uint64_t)k * kClaimCounters + claim_g;
+            if (cand < A.n_batches) { b = (uint32_t)cand; break; }
+            claim_g = (claim_g + 1u) % kClaimCounters;
+            claim_tries++;
+          }
           if (b >= A.n_batches) {
             none = true;
           } else if (A.batch_start) {
@@ -615,18 +636,27 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
 
   if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(wall_clock64() - tile_t0);
 
-  // ---- ray counters: one atomic per wave and kind
+  // ---- ray counters: per wave ...
   for (int off = 32; off > 0; off >>= 1) {
     n_primary += (uint32_t)__shfl_down((int)n_primary, off);
     n_shadow += (uint32_t)__shfl_down((int)n_shadow, off);
     n_reflect += (uint32_t)__shfl_down((int)n_reflect, off);
     n_hits += (uint32_t)__shfl_down((int)n_hits, off);
   }
+  // ... summed over the block (in the first bytes of the operand-stack lengths, each wave in the slots of
+  // its own lanes: the other waves may still be tracing) and stored per block; the host adds the blocks
+  // up.  Atomics on four device-wide counters, one set per wave, took 0.24 ms of every launch.
+  {
+    uint32_t* __restrict__ part = (uint32_t*)lens + (tid / kWave) * (kWave / 2);
+    if (lane == 0) { part[0] = n_primary; part[1] = n_shadow; part[2] = n_reflect; part[3] = n_hits; }
+    __syncthreads();
+    if (tid < 4) {
+      unsigned long long sum = 0;
+      for (int w = 0; w < kBlock / kWave; w++) sum += ((const uint32_t*)lens)[w * (kWave / 2) + tid];
+      A.block_counts[(size_t)blockIdx.x * 4 + tid] = sum;
+    }
+  }
   if (lane == 0) {
-    atomicAdd(&A.ray_counts[0], (unsigned long long)n_primary);
-    atomicAdd(&A.ray_counts[1], (unsigned long long)n_shadow);
-    atomicAdd(&A.ray_counts[2], (unsigned long long)n_reflect);
-    atomicAdd(&A.ray_counts[3], (unsigned long long)n_hits);
     DIAG(shade_args->diag_waves[wave * kDiagWaveSlots + 8] = w_start; shade_args->diag_waves[wave * kDiagWaveSlots + 9] = wall_clock64();
          shade_args->diag_waves[wave * kDiagWaveSlots + 10] = w_tiles;)
     DIAG(atomicAdd(&A.diag[0], dg.t_refill); atomicAdd(&A.diag[1], dg.t_trav); atomicAdd(&A.diag[2], dg.t_after);
@@ -763,7 +793,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     HIP_TRY(hipMalloc(&out->d_leaf_surf, leaf_surf.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(out->d_leaf_surf, leaf_surf.data(), leaf_surf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  if (!out->d_counters) HIP_TRY(hipMalloc(&out->d_counters, 512));
+  if (!out->d_counters) HIP_TRY(hipMalloc(&out->d_counters, kCountersBytes));
   if (!out->ev_start) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -855,7 +885,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // ---- launch geometry: a persistent grid sized to what the device keeps resident
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-  const size_t lens_bytes = (((size_t)H.max_stack * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
+  const size_t lens_bytes = (((size_t)(H.max_stack ? H.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
   if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
   int blocks_per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<true>, kBlock, lens_bytes));
@@ -888,6 +918,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   }
   const uint64_t need = (n_slots + kBlock - 1) / kBlock;
   if (grid > need) grid = need;
+  if (grid > kMaxGridBlocks) grid = kMaxGridBlocks;
   if (grid < 1) grid = 1;
 
   // ---- workspace
@@ -959,11 +990,11 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(d_tile_dbg, 0, n_tiles * 4 * sizeof(unsigned long long), stream));
   A.tile_dbg = d_tile_dbg;
 #endif
-  A.next_slot = (unsigned int*)s->d_counters;
-  A.ray_counts = (unsigned long long*)((uint8_t*)s->d_counters + 8);
-  A.diag = (unsigned long long*)((uint8_t*)s->d_counters + 64);
+  A.next_batch = (unsigned int*)s->d_counters;
+  A.block_counts = (unsigned long long*)((uint8_t*)s->d_counters + kOffBlockCounts);
+  A.diag = (unsigned long long*)((uint8_t*)s->d_counters + kOffDiag);
 
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 256, stream));
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, kOffShadeArgs, stream));  // claim and diagnostic counters; every block writes its counts
   ShadeArgs SA;
   std::memset(&SA, 0, sizeof(SA));
   for (int i = 0; i < 3; i++) SA.amb[i] = p.amb[i];
@@ -986,19 +1017,23 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long), stream));
   SA.diag_waves = d_diag_waves;
 #endif
-  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + 256, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + kOffShadeArgs, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   if (A.lds_ctx)
     hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + kOffShadeArgs), A);
   else
     hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + 256), A);
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
-  unsigned long long counts[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(counts, (uint8_t*)s->d_counters + 8, 32, hipMemcpyDeviceToHost, stream));
+  std::vector<unsigned long long> per_block((size_t)grid * 4);
+  HIP_TRY(hipMemcpyAsync(per_block.data(), (uint8_t*)s->d_counters + kOffBlockCounts, per_block.size() * sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  unsigned long long counts[4] = {0, 0, 0, 0};
+  for (size_t b = 0; b < (size_t)grid; b++)
+    for (int k = 0; k < 4; k++) counts[k] += per_block[b * 4 + k];
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
   if ((s->order_state == 1 || s->order_state == 2) && way == s->order_state) {
@@ -1106,7 +1141,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
 #ifdef GMLRT_DIAG
   {
     unsigned long long dgv[16];
-    HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + 64, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dgv, (uint8_t*)s->d_counters + kOffDiag, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     {
       std::vector<unsigned long long> per_wave(lanes / kWave * kDiagWaveSlots);
       HIP_TRY(hipMemcpy(per_wave.data(), d_diag_waves, per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1143,7 +1178,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     }
     {
       unsigned long long ex[9];
-      HIP_TRY(hipMemcpy(ex, (uint8_t*)s->d_counters + 64 + 16 * 8, 8 * sizeof(ex[0]), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(ex, (uint8_t*)s->d_counters + kOffDiag + 16 * 8, 8 * sizeof(ex[0]), hipMemcpyDeviceToHost));
       ex[8] = dgv[6] - ex[6] - ex[7];
       const double entered = (double)(dgv[4] - dgv[5]) > 0 ? (double)(dgv[4] - dgv[5]) : 1.0, nl = (double)dgv[6] > 0 ? (double)dgv[6] : 1.0;
       std::fprintf(stderr, "[gmlrt diag] lanes whose ray meets an entered bound %.1f; per leaf test: lanes taking part %.1f, with an Entry %.1f\n",
