@@ -90,6 +90,7 @@ struct KArgs {
   uint32_t vm_lds_off;   // byte offset of that LDS region (after the operand-stack lengths)
   uint32_t lds_ctx;      // 1: the region also holds the hot fields of the shading context
   const uint32_t* tile_order;  // tile to render for the i-th hand-out; null: i itself
+  uint32_t stride;             // no tile_order: hand-out i renders tile (i * stride) % n_tiles (1: image order)
   const uint32_t* batch_start; // hand-outs [batch_start[b], batch_start[b + 1]) make up batch b; null: kTileBatch each
   uint32_t n_batches;
   uint32_t n_tiles;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         batch_pos++;
         tile_base = t;
         tile_left = 64u;
-        cur_tile = A.tile_order ? A.tile_order[t >> 6] : (t >> 6);
+        cur_tile = A.tile_order ? A.tile_order[t >> 6] : (uint32_t)(((uint64_t)(t >> 6) * A.stride) % A.n_tiles);
         tile_t0 = now;
         DIAG(w_tiles++;)
       }
@@ -982,6 +983,18 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
   A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img : nullptr;
   A.n_tiles = (uint32_t)n_tiles;
+  A.stride = 1;
+  static const bool no_stride = std::getenv("GMLRT_IMAGE_ORDER") != nullptr;  // tuning runs
+  if (way == 0 && !s->learn_order && !no_stride && H.n_leaves > 16) {
+    // A handle that renders once knows no tile costs.  In image order the dear tiles of a frame tend to
+    // sit together (the lower rows of a scene on a floor) and the launch ends on them; a golden-ratio
+    // stride, made coprime with the tile count, spreads neighbours over the whole launch instead
+    // (chess 4K: 7.5 -> 6.4 ms, fractal 2.45 -> 2.15 ms; a scene of a few primitives loses 3 %).
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    uint64_t st = (uint64_t)((double)n_tiles * 0.6180339887) | 1ull;
+    while (st > 1 && gcd(st, n_tiles) != 1) st += 2;
+    if (st < n_tiles) A.stride = (uint32_t)st;
+  }
   A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
   A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
 #ifdef GMLRT_DIAG
@@ -1106,7 +1119,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       // launch (two dozen a wave), and few enough that the claims, which the memory system serves one at
       // a time (about 14 ns each), stay a small part of the launch: at most one claim per 56 ns of it.
       unsigned long long n_target = waves * 24ull;
-      const unsigned long long by_claims = (unsigned long long)((double)ms * 1e6 / 56.0) + 1ull;
+      static const double claim_ns = [] { const char* e = std::getenv("GMLRT_CLAIM_NS"); return e ? std::atof(e) : 56.0; }();  // tuning runs
+      const unsigned long long by_claims = (unsigned long long)((double)ms * 1e6 / claim_ns) + 1ull;
       if (n_target > by_claims) n_target = by_claims;
       const unsigned long long target = total / n_target + 1ull;
       auto build = [&](bool in_learnt_order, void* d_table, uint32_t* n_out) -> hipError_t {
