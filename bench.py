@@ -184,7 +184,10 @@ def main():
                          "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 5),
                          "kernel": "render_kernel", "kernel_ms": round(my_kernel_ms, 4),
                          "kernel_Mrays_per_s": round(my_rays / (my_kernel_ms * 1e-3) / 1e6, 3),
-                         "traffic": traffic, "valu_busy_measured": valu_busy},
+                         "traffic": traffic, "valu_busy_measured": valu_busy,
+                         "note": "achieved counts the reference's brute-force work per ray (every primitive tested, "
+                                 "15328 flops on this scene), most of which the bounds cull: it is a rate of useful "
+                                 "results, not of executed flops; valu_busy_measured is the physical VALU issue utilisation"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
