@@ -50,17 +50,21 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
   uint32_t pc = 0;       // byte offset of the current record (wave-uniform)
   // for the box tests; a zero component gives +-inf, which the slab arithmetic below handles
   const V3 inv_d = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
   for (;;) {
     // The first 64 bytes of the record, whatever its kind, in one scalar load: fetching the
     // kind first and the operands after the branch on it would be two dependent round trips
     // per record.  (The program is padded so that this never reads past its buffer.)
-    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-    const u32x16 R = *(const u32x16*)(const void*)(prog + pc);
-#define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
-    const uint32_t kf = R[0];
-    const uint32_t kind = kf & 0xFu;
+    u32x16 R = *(const u32x16*)(const void*)(prog + pc);
+    uint32_t kf = R[0];
+    uint32_t kind = kf & 0xFu;
     level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);  // wave-uniform by construction: say so
-    if (kind == kRecBox || kind == kRecBound) {
+    // Bounds come in runs (the way down a hierarchy) and change nothing a lane carries, only where
+    // the wave reads next: they get a loop of their own, whose only state is scalar.  (In one loop
+    // with the other record kinds every bound record paid for copying the lanes' candidate, flags
+    // and stack height from one iteration to the next.)
+    while (kind == kRecBox || kind == kRecBound) {
       // A bound in front of a subtree: if no lane's ray comes near it, every list below is
       // empty.  Under the union frontier that means "nothing to take"; inside a frontier
       // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
@@ -99,14 +103,19 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       }
       DIAG(dg.n_bound++;)
       DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
-      if (__ballot(hit)) { pc = next; continue; }
-      DIAG(dg.n_skip++;)
-      if (!(kf & kRecFlag)) {
-        lens[level * kBlock + tid] = 0;
-        level++;
+      if (__ballot(hit)) {
+        pc = next;
+      } else {
+        DIAG(dg.n_skip++;)
+        if (!(kf & kRecFlag)) {
+          lens[level * kBlock + tid] = 0;
+          level++;
+        }
+        pc = R[1];
       }
-      pc = R[1];
-      continue;
+      R = *(const u32x16*)(const void*)(prog + pc);
+      kf = R[0];
+      kind = kf & 0xFu;
     }
     if (kind == kRecLeaf) {
       // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
