@@ -908,7 +908,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
                                  : (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu;
     A.lds_ctx = lens_bytes + hot_bytes <= per_block ? 1u : 0u;
   }
-  if (A.lds_ctx) n_vm_fast = s->n_vm_regs < (uint32_t)kHotFields ? s->n_vm_regs : (uint32_t)kHotFields;
+  // (six of the region's slots are kept for the programs' results: gmlrt_shade.hpp)
+  if (A.lds_ctx) n_vm_fast = s->n_vm_regs < (uint32_t)kHotFields - 6u ? s->n_vm_regs : (uint32_t)kHotFields - 6u;
   const size_t lds_bytes = lens_bytes + (A.lds_ctx ? hot_bytes : n_vm_fast * kBlock * sizeof(uint64_t));
   A.n_vm_fast = (uint32_t)n_vm_fast;
   A.vm_lds_off = (uint32_t)lens_bytes;

@@ -504,7 +504,7 @@ void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v
     return;
   }
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
-  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
   surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R);
 }
 
@@ -537,8 +537,8 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
   std::vector<uint8_t> rec;
   expand_surface(p.code.data(), p.consts.data(), rec);
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
-  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
-  surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, out, R);
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
+  surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, VmArrayOut{out}, R);
 }
 
 // ---- specialisation of an expanded program for one value of `face`.
@@ -671,8 +671,8 @@ void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, do
   expand_surface(p.code.data(), p.consts.data(), rec);
   specialize_surface(rec.data(), face, spec);
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
-  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true};
-  surface_stream_vm<true>((const SurfInstr*)spec.data(), face, u, v, out, R);
+  const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
+  surface_stream_vm<true>((const SurfInstr*)spec.data(), face, u, v, VmArrayOut{out}, R);
 }
 
 // ============================================================== flattening

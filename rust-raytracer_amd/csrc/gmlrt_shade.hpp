@@ -91,7 +91,9 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
   // scalar loads); a lane keeps the result of its own program.  Lanes without a hit run
   // along on zeros without storing anything; the bytecode has no trapping operation.
   DIAG(tq1 = __builtin_readcyclecounter();)
-  double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // The results (colour, kd, ks, n) go straight to their hot fields H_SC .. H_N, stored only by the
+  // lanes that run their own program.  With the hot fields in LDS those six slots lie inside the region
+  // the interpreter's registers use, so registers 6 and up are kept six slots further on.
   {
     typedef GMLRT_AS(3) uint64_t* LdsP;
     typedef GMLRT_AS(1) uint64_t* GlobalP;
@@ -99,7 +101,16 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     const VmRegs<LdsP, GlobalP> R = {
         (LdsP)(uintptr_t)vm_fast_v, (uint32_t)kBlock, SA->n_vm_fast,
         (GlobalP)(uintptr_t)(ctx_v + (size_t)(SA->ctx_fields - GMLRT_SURF_MAX_REGS) * kWave), (uint32_t)kWave,
-        shade};  // the region holds live context fields of the lanes that are not shading a hit
+        shade,  // the region holds live context fields of the lanes that are not shading a hit
+        kLds ? (uint32_t)H_SC : (uint32_t)GMLRT_SURF_MAX_REGS, kLds ? 6u : 0u};
+    struct HotOut {
+      double* hot;
+      bool mine;
+      __device__ void put(uint32_t first, double a, double b, double c) const {
+        if (mine) { HOT(H_SC + first) = a; HOT(H_SC + first + 1) = b; HOT(H_SC + first + 2) = c; }
+      }
+    };
+    static_assert(H_KD == H_SC + 3 && H_KS == H_SC + 4 && H_N == H_SC + 5, "result slots 0..5 map onto H_SC..H_N");
     const ProgP progs = (ProgP)(uintptr_t)wave_uniform(SA->surf_prog);
     const bool all_fast = SA->vm_all_fast != 0;
     bool need = shade && mysurf != kNoSurfProg;
@@ -109,14 +120,10 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       DIAG(vm_runs++;)
       const int src = __builtin_ctzll(todo);
       const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mysurf, src);
-      double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (all_fast) surface_stream_vm<true>(progs + cur, (int64_t)face, u, v, t6, R);
-      else surface_stream_vm<false>(progs + cur, (int64_t)face, u, v, t6, R);
-      if (need && mysurf == cur) {
-#pragma unroll
-        for (int q = 0; q < 6; q++) s6[q] = t6[q];
-        need = false;
-      }
+      const HotOut out = {hot, need && mysurf == cur};
+      if (all_fast) surface_stream_vm<true>(progs + cur, (int64_t)face, u, v, out, R);
+      else surface_stream_vm<false>(progs + cur, (int64_t)face, u, v, out, R);
+      if (mysurf == cur) need = false;
       todo = __ballot(need);
     }
     DIAG(tq_runs = vm_runs; tq_lanes = vm_lanes;)
@@ -129,10 +136,8 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     if (mysurf == kNoSurfProg) {
       const uint64_t* kc = const_space(wave_uniform(SA->consts)) + L->surf_const;
 #pragma unroll
-      for (int q = 0; q < 6; q++) s6[q] = vm_as_f64(kc[q]);
+      for (int q = 0; q < 6; q++) HOT(H_SC + q) = vm_as_f64(kc[q]);
     }
-    HOT(H_SC) = s6[0]; HOT(H_SC + 1) = s6[1]; HOT(H_SC + 2) = s6[2];
-    HOT(H_KD) = s6[3]; HOT(H_KS) = s6[4]; HOT(H_N) = s6[5];
     HOT_SET3(H_DIFF, (V3{0.0, 0.0, 0.0}));
     HOT_SET3(H_SPEC, (V3{0.0, 0.0, 0.0}));
     const double* m = L->m;

@@ -64,18 +64,23 @@ struct VmRegs {
   SlowP slow;
   uint32_t slow_stride;
   bool writable;  // false: this lane only runs along with its wave and must not touch the storage
+  // fast registers gap_at and up sit gap_len slots further on (the device keeps the slots in between
+  // for the program's results); n_fast counts registers, not slots
+  uint32_t gap_at, gap_len;
 };
+template <class RegsT>
+GMLRT_HD uint32_t vm_slot(const RegsT& R, uint32_t i) { return i >= R.gap_at ? i + R.gap_len : i; }
 // kAllFast: the caller guarantees that every register the program names is below n_fast.
 template <bool kAllFast, class RegsT>
 GMLRT_HD uint64_t vm_get(const RegsT& R, uint32_t i) {
-  if (kAllFast) return R.fast[(size_t)i * R.fast_stride];
-  if (i < R.n_fast) return R.fast[(size_t)i * R.fast_stride];
+  if (kAllFast) return R.fast[(size_t)vm_slot(R, i) * R.fast_stride];
+  if (i < R.n_fast) return R.fast[(size_t)vm_slot(R, i) * R.fast_stride];
   return R.slow[(size_t)i * R.slow_stride];
 }
 template <bool kAllFast, class RegsT>
 GMLRT_HD void vm_set(const RegsT& R, uint32_t i, uint64_t v) {
   if (!R.writable) return;
-  if (kAllFast || i < R.n_fast) R.fast[(size_t)i * R.fast_stride] = v;
+  if (kAllFast || i < R.n_fast) R.fast[(size_t)vm_slot(R, i) * R.fast_stride] = v;
   else R.slow[(size_t)i * R.slow_stride] = v;
 }
 template <bool kAllFast, class ConstP, class RegsT>
@@ -166,8 +171,16 @@ GMLRT_HD SurfInstr vm_fetch(ProgP prog, uint32_t pc) {
   return I;
 }
 
-template <bool kAllFast, class ProgP, class RegsT>
-GMLRT_HD void surface_stream_vm(ProgP prog, int64_t face, double u, double v, double out[6], const RegsT R) {
+// Where a program's results go: put(first, a, b, c) stores result slots first .. first + 2 (first is 0
+// for the colour, 3 for kd, ks, n).  The host and the plain interpreter collect them in an array; the device
+// stores them where the shading code reads them, so that no result is carried through the interpreter loop.
+struct VmArrayOut {
+  double* out;
+  GMLRT_HD void put(uint32_t first, double a, double b, double c) const { out[first] = a; out[first + 1] = b; out[first + 2] = c; }
+};
+
+template <bool kAllFast, class ProgP, class RegsT, class OutT>
+GMLRT_HD void surface_stream_vm(ProgP prog, int64_t face, double u, double v, const OutT out, const RegsT R) {
   vm_set<kAllFast>(R, 0, (uint64_t)face);
   vm_set<kAllFast>(R, 1, vm_from_f64(u));
   vm_set<kAllFast>(R, 2, vm_from_f64(v));
@@ -215,8 +228,7 @@ GMLRT_HD void surface_stream_vm(ProgP prog, int64_t face, double u, double v, do
       case GMLRT_SOP_OUT: {
         const uint64_t c = (head & GMLRT_SI_IMM_C) ? I.c : vm_get<kAllFast>(R, (uint32_t)I.c);
         const double fc = vm_as_f64(c);
-        if (dst == 0) { out[0] = fa; out[1] = fb; out[2] = fc; }
-        else if (dst == 3) { out[3] = fa; out[4] = fb; out[5] = fc; }
+        if (dst == 0 || dst == 3) out.put(dst, fa, fb, fc);
         I = next;
         continue;
       }
