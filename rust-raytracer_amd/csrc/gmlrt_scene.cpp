@@ -597,6 +597,14 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
   uint64_t value[GMLRT_SURF_MAX_REGS] = {0};
   known[0] = true;
   value[0] = (uint64_t)face;
+  // copies: alias[r] = s while register r holds what a move took from register s and neither has been
+  // written since; readers of r are pointed at s, which leaves the move without readers (dropped below)
+  int alias[GMLRT_SURF_MAX_REGS];
+  for (int& a : alias) a = -1;
+  auto written = [&](uint32_t r) {
+    alias[r] = -1;
+    for (int& a : alias) if (a == (int)r) a = -1;
+  };
   std::vector<SurfInstr> fwd;
   for (size_t pc = 0;; pc++) {
     SurfInstr I = prog[pc];
@@ -610,6 +618,8 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
       if (!(I.head & imm[k]) && known[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)]) {
         *slot[k] = value[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)];
         I.head |= imm[k];
+      } else if (!(I.head & imm[k]) && alias[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)] >= 0) {
+        *slot[k] = (uint64_t)alias[*slot[k] & (GMLRT_SURF_MAX_REGS - 1)];
       }
     }
     if (op == GMLRT_SOP_OUT) { fwd.push_back(I); continue; }
@@ -621,7 +631,7 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
         const bool take_b = same || I.a != 0;
         const uint64_t v = take_b ? I.b : I.c;
         const bool v_imm = (I.head & (take_b ? imm[1] : imm[2])) != 0;
-        if (v_imm) { known[dst] = true; value[dst] = v; continue; }
+        if (v_imm) { known[dst] = true; value[dst] = v; written(dst); continue; }
         if ((v & (GMLRT_SURF_MAX_REGS - 1)) == dst) continue;  // onto itself: the value is unknown as before
         SurfInstr M;
         std::memset(&M, 0, sizeof(M));
@@ -629,15 +639,22 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
         M.a = v;
         fwd.push_back(M);
         known[dst] = false;
+        written(dst);
+        alias[dst] = (int)(v & (GMLRT_SURF_MAX_REGS - 1));
         continue;
       }
     } else {
       bool all_imm = true;
       for (int k = 0; k < 3; k++) all_imm = all_imm && (I.head & imm[k]);
       uint64_t res;
-      if (all_imm && surf_fold(op, I.a, I.b, &res)) { known[dst] = true; value[dst] = res; continue; }
+      if (all_imm && surf_fold(op, I.a, I.b, &res)) { known[dst] = true; value[dst] = res; written(dst); continue; }
     }
     known[dst] = false;
+    written(dst);
+    if (op == GMLRT_SOP_MOV && !(I.head & imm[0])) {
+      if ((I.a & (GMLRT_SURF_MAX_REGS - 1)) == dst) continue;  // a move onto itself
+      alias[dst] = (int)(I.a & (GMLRT_SURF_MAX_REGS - 1));
+    }
     fwd.push_back(I);
   }
   // backward: drop what no OUT depends on
