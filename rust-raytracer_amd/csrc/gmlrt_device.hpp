@@ -88,6 +88,10 @@ struct DeviceScene {
   void* d_tile_batch_img = nullptr;      // way 2's batch table
   uint32_t n_batches_img = 0;
   gmlrt_params order_key{};     // the launch parameters the order belongs to (ambient zeroed)
+  void* h_staging = nullptr;    // page-locked host memory for the launch record and the per-block ray counts
+  int dev_cus = 0;              // device facts, asked once: compute units, LDS per block and per unit,
+  size_t dev_lds_block = 0, dev_lds_cu = 0;
+  int dev_blocks_per_cu = 0;    // resident blocks per unit for this scene's LDS need
   void* ev_start = nullptr;     // hipEvent_t pair used to time the kernel
   void* ev_stop = nullptr;
 };

@@ -54,6 +54,7 @@ constexpr uint32_t kClaimCounters = 8, kClaimStride = 4096;
 constexpr size_t kOffDiag = (size_t)kClaimCounters * kClaimStride, kOffShadeArgs = kOffDiag + 256, kOffBlockCounts = kOffDiag + 1024;
 constexpr size_t kMaxGridBlocks = 8192;
 constexpr size_t kCountersBytes = kOffBlockCounts + kMaxGridBlocks * 4 * sizeof(unsigned long long);
+constexpr size_t kStagingBytes = 1024 + kMaxGridBlocks * 4 * sizeof(unsigned long long);  // host side: ShadeArgs, then the block counts
 [[maybe_unused]] constexpr int kDiagWaveSlots = 12;  // diagnostic build: counters per wave
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
@@ -740,6 +741,7 @@ void free_workspace(DeviceScene* s) {
   (void)hipFree(s->d_tile_order);
   (void)hipFree(s->d_tile_batch);
   (void)hipFree(s->d_tile_batch_img);
+  if (s->h_staging) (void)hipHostFree(s->h_staging);
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
 }
@@ -818,7 +820,7 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.d_ev_dist = s->d_ev_dist; spare.d_ev_meta = s->d_ev_meta; spare.d_ctx = s->d_ctx;
   spare.d_counters = s->d_counters;
   spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc; spare.lanes_alloc = s->lanes_alloc;
-  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img; spare.tiles_alloc = s->tiles_alloc;
+  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img; spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
   {
@@ -884,13 +886,22 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (rows == 0) return "";
 
   // ---- launch geometry: a persistent grid sized to what the device keeps resident
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
   const size_t lens_bytes = (((size_t)(H.max_stack ? H.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
   if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
-  int blocks_per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<true>, kBlock, lens_bytes));
-  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  // (asked once per handle: the two queries cost tens of microseconds, a fifth of a simple frame)
+  if (s->dev_cus == 0) {
+    hipDeviceProp_t q;
+    HIP_TRY(hipGetDeviceProperties(&q, s->device));
+    int b = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true>, kBlock, lens_bytes));
+    s->dev_cus = q.multiProcessorCount;
+    s->dev_lds_block = q.sharedMemPerBlock;
+    s->dev_lds_cu = q.maxSharedMemoryPerMultiProcessor;
+    s->dev_blocks_per_cu = b < 1 ? 1 : b;
+  }
+  struct { int multiProcessorCount; size_t sharedMemPerBlock, maxSharedMemoryPerMultiProcessor; } prop = {
+      s->dev_cus, s->dev_lds_block, s->dev_lds_cu};
+  const int blocks_per_cu = s->dev_blocks_per_cu;
   // The surface bytecode's registers go to whatever LDS is left at that occupancy.
   size_t n_vm_fast = s->n_vm_regs;
   {
@@ -1031,7 +1042,10 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long), stream));
   SA.diag_waves = d_diag_waves;
 #endif
-  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + kOffShadeArgs, &SA, sizeof(SA), hipMemcpyHostToDevice, stream));
+  // through page-locked memory: copies to and from pageable memory are staged and wait
+  if (!s->h_staging) HIP_TRY(hipHostMalloc(&s->h_staging, kStagingBytes, hipHostMallocDefault));
+  std::memcpy(s->h_staging, &SA, sizeof(SA));
+  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + kOffShadeArgs, s->h_staging, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   if (A.lds_ctx)
     hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
@@ -1041,8 +1055,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
-  std::vector<unsigned long long> per_block((size_t)grid * 4);
-  HIP_TRY(hipMemcpyAsync(per_block.data(), (uint8_t*)s->d_counters + kOffBlockCounts, per_block.size() * sizeof(unsigned long long),
+  const unsigned long long* per_block = (const unsigned long long*)((uint8_t*)s->h_staging + 1024);
+  HIP_TRY(hipMemcpyAsync((void*)per_block, (uint8_t*)s->d_counters + kOffBlockCounts, (size_t)grid * 4 * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   unsigned long long counts[4] = {0, 0, 0, 0};
