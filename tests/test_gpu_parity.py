@@ -77,6 +77,29 @@ def test_row_partitions_reassemble(gmlrt):
     scene.close()
 
 
+@pytest.mark.parametrize("name,size,depth", [("chess", (3840, 2160), 5), ("large", (7680, 4320), 8), ("fractal", (1921, 1081), 3)])
+def test_every_way_of_handing_out_tiles_gives_the_same_image(gmlrt, name, size, depth):
+    # A scene handle deals its pixel tiles differently from launch to launch (image order in fixed batches while it
+    # times them, then the learnt order and the image order with cost-balanced batches on trial, then the fastest).
+    # Every launch must render every pixel exactly once: same bytes, same ray counts, also against the one-shot
+    # entry point, whose handle strides over the tiles.  Sizes: the two full-size configurations, and one whose
+    # width and height leave ragged tiles.
+    import torch
+    call = gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].with_overrides(size[0], size[1], depth)
+    ref, _, st_ref = gmlrt.render(call)
+    scene = gmlrt.DeviceScene(call.blob, 0)
+    buf = torch.empty((size[1], size[0], 3), dtype=torch.uint8, device="cuda:0")
+    for launch in range(6):
+        buf.fill_(0x5A)  # a pixel nobody writes would keep this
+        st = scene.render_into(call.params, buf.data_ptr())
+        img = buf.cpu().numpy()
+        assert (img == ref).all(), (name, launch)
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits) == \
+               (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits), (name, launch)
+    scene.close()
+    assert st_ref.rays_primary == size[0] * size[1]
+
+
 def test_repeated_render_is_deterministic(gmlrt):
     prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
     a, _, sa = gmlrt.render(prog.calls[0])
@@ -117,6 +140,21 @@ def test_full_size_rows_against_oracle(gmlrt, oracle):
     rows = list(range(90, 2160, 180))
     frac1, maxd, ndiff = image_diff(img[rows], ref)
     print("4K rows: within1=%.6f max=%d differing=%d" % (frac1, maxd, ndiff))
+    assert frac1 >= 0.999 and maxd <= 8
+
+
+@pytest.mark.parametrize("name,size,depth,step", [("large", (7680, 4320), 8, 240), ("fractal", (3840, 2160), 3, 360),
+                                                  ("cone-fractal", (3840, 2160), 3, 360), ("house", (3840, 2160), 3, 180)])
+def test_other_configurations_full_size_rows_against_oracle(gmlrt, oracle, name, size, depth, step):
+    # the other configuration scenes at their full sizes: rows spread over the image against the oracle
+    path = os.path.join(SCENES, name + ".gml")
+    call = gmlrt.Program(path=path).calls[0].with_overrides(size[0], size[1], depth)
+    img, _, _ = gmlrt.render(call)
+    y0 = step // 2
+    ref, _, _ = oracle.OracleProgram(path=path).render(0, w=size[0], h=size[1], depth=depth, y0=y0, y1=size[1], ystep=step, threads=16)
+    rows = list(range(y0, size[1], step))
+    frac1, maxd, ndiff = image_diff(img[rows], ref)
+    print("%s %dx%d rows: within1=%.6f max=%d differing=%d" % (name, size[0], size[1], frac1, maxd, ndiff))
     assert frac1 >= 0.999 and maxd <= 8
 
 
