@@ -16,12 +16,13 @@ namespace gmlrt {
 // kRecFlag in bit 8, a leaf's primitive type in bits 18..16.
 constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5;
 constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
-struct ProgBound {   // 48 bytes
+struct ProgBound {   // 64 bytes
   uint32_t kind;
   uint32_t skip_to;  // byte offset of the first record after the bounded subtree
   double center[3];
   double radius2;
   double radius;
+  double pad[2];     // to 64 bytes: a record fetch that straddles two cache lines is two requests
 };
 struct ProgBox {     // 64 bytes: the same as ProgBound with the subtree's box instead of its sphere
   uint32_t kind;
@@ -30,18 +31,19 @@ struct ProgBox {     // 64 bytes: the same as ProgBound with the subtree's box i
   double hi[3];
   uint64_t pad;
 };
-struct ProgLeaf {    // 112 bytes
+struct ProgLeaf {    // 128 bytes
   uint32_t kind;
   uint32_t leaf;     // index into the blob's leaf section
   double inv_m[12];
   uint64_t pad;
+  uint64_t pad2[2];  // to 128 bytes
 };
 struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags), take, end
   uint32_t kind;
   uint32_t arg;
   uint64_t pad;
 };
-static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 48 && sizeof(ProgLeaf) == 112 && sizeof(ProgSmall) == 16, "record sizes");
+static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 64 && sizeof(ProgLeaf) == 128 && sizeof(ProgSmall) == 16, "record sizes");
 std::vector<uint8_t> derive_stream_program(const void* blob);
 // Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h): every leaf's program
 // specialised for each face its primitive can report, identical results stored once;
