@@ -233,40 +233,50 @@ __device__ inline void merge_cx(double& d0, uint32_t& m0, double& d1, uint32_t& 
   const uint32_t ml = swap ? m1 : m0, mh = swap ? m0 : m1;
   d0 = dl; d1 = dh; m0 = ml; m1 = mh;
 }
+// kN = 4: up to 4 + 4 events; kN = 2: up to 2 + 2 (two primitives), the most common case, with a third of
+// the comparators and half the loads and sweep steps.
+template <int kN>
 __device__ __noinline__ uint32_t merge_small(uint32_t rule, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
                                              uint32_t a0, uint32_t la, uint32_t lb) {
   double* __restrict__ evD = global_space(evD_v);
   uint32_t* __restrict__ evM = global_space(evM_v);
   const uint32_t b0 = a0 + la;
-  double d[8];
-  uint32_t m[8];
+  double d[2 * kN];
+  uint32_t m[2 * kN];
 #pragma unroll
-  for (uint32_t i = 0; i < 4; i++) {
-    // clamped index: always a slot of the list, so all sixteen loads can be in flight together
+  for (uint32_t i = 0; i < (uint32_t)kN; i++) {
+    // clamped index: always a slot of the list, so all the loads can be in flight together
     const uint32_t ia = a0 + (i < la ? i : la - 1u), ib = b0 + (i < lb ? i : lb - 1u);
     d[i] = evD[(size_t)ia * kWave];
     m[i] = evM[(size_t)ia * kWave];
-    d[4 + i] = evD[(size_t)ib * kWave];
-    m[4 + i] = evM[(size_t)ib * kWave];
+    d[kN + i] = evD[(size_t)ib * kWave];
+    m[kN + i] = evM[(size_t)ib * kWave];
   }
 #pragma unroll
-  for (uint32_t i = 0; i < 4; i++) {
+  for (uint32_t i = 0; i < (uint32_t)kN; i++) {
     if (i >= la) d[i] = __builtin_inf();
-    if (i >= lb) d[4 + i] = __builtin_inf();
+    if (i >= lb) d[kN + i] = __builtin_inf();
+    // the position in A ++ B, with B's numbered from 4 in both sizes (bit 2 = "from B")
     m[i] = (m[i] & ~(7u << kPosShift)) | (i << kPosShift);
-    m[4 + i] = (m[4 + i] & ~(7u << kPosShift)) | ((4u + i) << kPosShift);
+    m[kN + i] = (m[kN + i] & ~(7u << kPosShift)) | ((4u + i) << kPosShift);
   }
-  merge_cx(d[0], m[0], d[4], m[4]); merge_cx(d[1], m[1], d[5], m[5]);
-  merge_cx(d[2], m[2], d[6], m[6]); merge_cx(d[3], m[3], d[7], m[7]);
-  merge_cx(d[2], m[2], d[4], m[4]); merge_cx(d[3], m[3], d[5], m[5]);
-  merge_cx(d[1], m[1], d[2], m[2]); merge_cx(d[3], m[3], d[4], m[4]); merge_cx(d[5], m[5], d[6], m[6]);
+  if constexpr (kN == 4) {
+    merge_cx(d[0], m[0], d[4], m[4]); merge_cx(d[1], m[1], d[5], m[5]);
+    merge_cx(d[2], m[2], d[6], m[6]); merge_cx(d[3], m[3], d[7], m[7]);
+    merge_cx(d[2], m[2], d[4], m[4]); merge_cx(d[3], m[3], d[5], m[5]);
+    merge_cx(d[1], m[1], d[2], m[2]); merge_cx(d[3], m[3], d[4], m[4]); merge_cx(d[5], m[5], d[6], m[6]);
+  } else {
+    // odd-even merge of two sorted pairs
+    merge_cx(d[0], m[0], d[2], m[2]); merge_cx(d[1], m[1], d[3], m[3]);
+    merge_cx(d[1], m[1], d[2], m[2]);
+  }
   // the sweep of primitives.rs:262-313, as in merge_lists
   const uint32_t total = la + lb;
   uint32_t k = 0;
   bool in1 = false, in2 = false, inside = false;
   double prevt = 0.0;
 #pragma unroll
-  for (uint32_t n = 0; n < 8; n++) {
+  for (uint32_t n = 0; n < 2u * kN; n++) {
     if (n < total) {
       const bool from_b = ((m[n] >> kPosShift) & 4u) != 0;
       const uint32_t mm = m[n] & ~(7u << kPosShift);
@@ -296,8 +306,10 @@ __device__ __noinline__ uint32_t merge_small(uint32_t rule, double* __restrict__
 __device__ inline uint32_t merge_any(uint32_t rule, double* __restrict__ evD, uint32_t* __restrict__ evM, uint32_t a0,
                                      uint32_t la, uint32_t lb) {
   uint32_t out = 0;
-  const bool small = la <= 4u && lb <= 4u;
-  if (small) out = merge_small(rule, evD, evM, a0, la, lb);
+  // (callers enter with the lanes that have two non-empty lists; the size class is chosen for the wave)
+  const bool pair = la <= 2u && lb <= 2u, small = la <= 4u && lb <= 4u;
+  if (!__ballot(!pair)) out = merge_small<2>(rule, evD, evM, a0, la, lb);
+  else if (small) out = merge_small<4>(rule, evD, evM, a0, la, lb);
   else out = merge_lists(rule, evD, evM, a0, la, lb);
   return out;
 }
