@@ -163,3 +163,17 @@ def test_golden_regression(oracle, name):
     img, _, cnt = prog.render(0, w=meta["w"], h=meta["h"], depth=meta["depth"], threads=4)
     assert (img == ref).all()
     assert cnt == meta["counts"]
+
+
+def test_independent_python_restatement_agrees_bit_for_bit(oracle):
+    # tests/independent_spheres.py restates the reference's path for spheres.gml in plain Python, the scene written
+    # out by hand: no shared code with the oracle or with the GML front-end that builds the oracle's scene.  The
+    # two must give the same unquantised f64 pixels (same operations in the same order), bytes and ray counts.
+    import independent_spheres as ind
+    w, h = 200, 150
+    img, raw, cnt = ind.render(w, h)
+    ref, ref64, ref_cnt = oracle.OracleProgram(path=os.path.join(SCENES, "spheres.gml")).render(0, w=w, h=h, want_f64=True, threads=4)
+    assert (np.array(img, dtype=np.uint8) == ref).all()
+    assert (np.array(raw) == ref64).all()
+    assert cnt == {k: ref_cnt[k] for k in ("primary", "shadow", "reflect")}
+    assert cnt["shadow"] > 0 and cnt["reflect"] > 0
