@@ -264,6 +264,19 @@ def test_rarely_taken_paths(gmlrt, oracle, label, surf, scene):
     assert st.rays_shadow > 0 and st.rays_reflect > 0 and len(np.unique(img)) > 8
 
 
+def test_scene_of_the_independent_restatement(gmlrt, oracle):
+    # the all-primitives scene that tests/independent_render.py pins the oracle with, on the GPU
+    import independent_render as ind
+    text = ind.MIXED_GML % (320, 240)
+    img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print("mixed: differing=%d max=%d" % (ndiff, maxd), st.as_dict())
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert np.abs(f64 - ref64).max() <= 1e-9
+
+
 # The reference's other scene files (its gml/ directory): every `render` each program executes, at the
 # size and depth the file names.  They exercise what the seven configuration scenes do not: array `get`
 # inside surface functions (checked-cube, cube), closures as values (holes), clampf/frac (golf), several

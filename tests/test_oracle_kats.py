@@ -166,14 +166,30 @@ def test_golden_regression(oracle, name):
 
 
 def test_independent_python_restatement_agrees_bit_for_bit(oracle):
-    # tests/independent_spheres.py restates the reference's path for spheres.gml in plain Python, the scene written
-    # out by hand: no shared code with the oracle or with the GML front-end that builds the oracle's scene.  The
-    # two must give the same unquantised f64 pixels (same operations in the same order), bytes and ray counts.
-    import independent_spheres as ind
+    # tests/independent_render.py restates the reference's path in plain Python with the scenes built by hand: no
+    # shared code with the oracle or with the GML front-end that builds the oracle's scenes.  The two must give the
+    # same unquantised f64 pixels (same operations in the same order), bytes and ray counts.
+    import independent_render as ind
     w, h = 200, 150
-    img, raw, cnt = ind.render(w, h)
+    img, raw, cnt = ind.render(ind.build_spheres, w, h, 3, 90.0, (0.4, 0.4, 0.4))
     ref, ref64, ref_cnt = oracle.OracleProgram(path=os.path.join(SCENES, "spheres.gml")).render(0, w=w, h=h, want_f64=True, threads=4)
     assert (np.array(img, dtype=np.uint8) == ref).all()
     assert (np.array(raw) == ref64).all()
     assert cnt == {k: ref_cnt[k] for k in ("primary", "shadow", "reflect")}
     assert cnt["shadow"] > 0 and cnt["reflect"] > 0
+
+
+def test_independent_python_restatement_all_primitives_rules_and_lights(oracle):
+    # the same for a scene with a cube, sphere, cylinder, cone and two planes under scale / uscale / rotatex/y/z /
+    # translate, joined by difference, intersect and union, lit by a directional, a point and a spot light, with a
+    # surface function of face, u and v: the GML text goes to the oracle, the hand-built objects to the Python code
+    import independent_render as ind
+    w, h = 160, 120
+    img, raw, cnt = ind.render(ind.build_mixed, w, h, 2, 80.0, (0.2, 0.25, 0.3))
+    ref, ref64, ref_cnt = oracle.OracleProgram(text=ind.MIXED_GML % (w, h)).render(0, want_f64=True, threads=4)
+    got, raw = np.array(img, dtype=np.uint8), np.array(raw)
+    print("differing bytes", int((got != ref).sum()), "max |f64 diff|", float(np.abs(raw - ref64).max()), cnt)
+    assert cnt == {k: ref_cnt[k] for k in ("primary", "shadow", "reflect")}
+    assert (raw == ref64).all()
+    assert (got == ref).all()
+    assert cnt["shadow"] > 0 and cnt["reflect"] > 0 and len(np.unique(got)) > 50
