@@ -8,7 +8,10 @@
 // Parity status: the reference holds no image-level fixture for this path and
 // cannot be built in this environment (no Rust toolchain), so image-level parity
 // is UNPINNED.  What pins this file: the reference's own unit-test facts
-// (tests/test_oracle_kats.py restates them) and analytic closed forms.
+// (tests/test_oracle_kats.py restates them), analytic closed forms, and a second
+// restatement written separately in plain Python from the reference's sources
+// (tests/independent_render.py, scenes built by hand), which must give the same
+// f64 pixels bit for bit.
 //
 // Reference map (all under /root/reference/src):
 //   vecmath helpers            vecmath.rs:7-34 (+ crate vecmath 0.3.1 definitions)
