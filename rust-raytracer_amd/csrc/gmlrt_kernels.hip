@@ -44,6 +44,13 @@ constexpr uint32_t kCurExit = 1u << 24;   // current type after operator switche
 constexpr uint32_t kHitAny = 1u << 31;    // set in the meta word handed to after_traversal: the ray hit something
 constexpr int kCtxFixed = 24;             // f64 fields of the shading context before the bounce stack
 constexpr int kCtxPerLevel = 7;
+#ifndef GMLRT_TILE_W
+#define GMLRT_TILE_W 8
+#endif
+// pixels of a tile: one wave's worth.  Measured, chess / fractal 4K in Mrays/s: 4 x 16 pixels 5410 / 11780,
+// 8 x 8 5300 / 12190, 16 x 4 4790 / 11940, 32 x 2 4050 / 11090.
+constexpr uint32_t kTileW = GMLRT_TILE_W, kTileH = 64 / GMLRT_TILE_W;
+static_assert(kTileW * kTileH == 64, "a tile is one wave of pixels");
 constexpr uint32_t kTileBatch = 4;      // tiles per claim when no batch table is given
 constexpr uint32_t kTileBatchMax = 16;  // most tiles a batch of the table holds
 // Atomics on one address are served one after the other, device-wide (about 14 ns each, measured): the
@@ -595,8 +602,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         // slot -> 8x8 tile -> pixel of this partition's packed rows
         const uint32_t slot = tile_base + rank;
         const uint32_t tile = cur_tile, in = slot & 63u;
-        const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
-        const uint32_t yl = (tile / A.tiles_x) * 8u + (in >> 3);
+        const uint32_t x = (tile % A.tiles_x) * kTileW + (in % kTileW);
+        const uint32_t yl = (tile / A.tiles_x) * kTileH + (in / kTileW);
         if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
           uint32_t y = yl;
           if (A.nparts > 1) {
@@ -882,8 +889,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.nparts = nparts;
   const int64_t rows = gmlrt_part_rows(p.height, A.tile_rows, A.part, nparts);
   A.rows_part = (int32_t)rows;
-  A.tiles_x = (uint32_t)((p.width + 7) / 8);
-  const uint64_t tiles_y = (uint64_t)((rows + 7) / 8);
+  A.tiles_x = (uint32_t)((p.width + kTileW - 1) / kTileW);
+  const uint64_t tiles_y = (uint64_t)((rows + kTileH - 1) / kTileH);
   const uint64_t n_slots = (uint64_t)A.tiles_x * tiles_y * 64ull;
   if (n_slots >= 0xFFFF0000ull) return "image too large for one launch";
   A.n_slots = (uint32_t)n_slots;
