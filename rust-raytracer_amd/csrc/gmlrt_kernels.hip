@@ -1152,7 +1152,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       // Two limits on the number of batches: enough of them that the last ones even out the end of the
       // launch (two dozen a wave), and few enough that the claims, which the memory system serves one at
       // a time (about 14 ns each), stay a small part of the launch: at most one claim per 56 ns of it.
-      unsigned long long n_target = waves * 24ull;
+      static const unsigned long long per_wave = [] { const char* e = std::getenv("GMLRT_BATCHES_PER_WAVE"); return e ? (unsigned long long)std::atoi(e) : 24ull; }();  // tuning runs
+      unsigned long long n_target = waves * per_wave;
       static const double claim_ns = [] { const char* e = std::getenv("GMLRT_CLAIM_NS"); return e ? std::atof(e) : 56.0; }();  // tuning runs
       const unsigned long long by_claims = (unsigned long long)((double)ms * 1e6 / claim_ns) + 1ull;
       if (n_target > by_claims) n_target = by_claims;
