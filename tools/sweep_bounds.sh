@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 SCENE=${1:-scenes/chess.gml}
 : > gpurun_out/sweep_bounds.txt
-for op in 0.3 0.5 0.7 0.9; do
-  for lf in 0.1 0.25 0.5 0.8; do
+for op in ${OPS:-0.3 0.5 0.7 0.9}; do
+  for lf in ${LEAVES:-0.1 0.25 0.5 0.8}; do
     for bias in 0.8; do
       GMLRT_BOUND_OP_RATIO=$op GMLRT_BOUND_LEAF_RATIO=$lf GMLRT_BOX_BIAS=$bias timeout -k 10 120 python bench.py --scene $SCENE --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/sweep_one.json 2> gpurun_out/sweep_one.err || { echo "op $op leaf $lf FAILED" >> gpurun_out/sweep_bounds.txt; exit 1; }
       python - "$op" "$lf" "$bias" <<'PY' >> gpurun_out/sweep_bounds.txt
