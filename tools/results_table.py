@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One row per configuration scene for the results table: kernel time and throughput on one MI355X through the C ABI,
+the CPU oracle on a row subset beside it, and the parity of those rows.
+Usage on the GPU box: python tools/results_table.py > gpurun_out/results_table.md"""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import gmlrt, oracle_py
+import bench
+
+CONFIGS = [("spheres", 640, 480, None), ("spheres", 3840, 2160, None), ("chess", 3840, 2160, 5), ("fractal", 3840, 2160, None),
+           ("cone-fractal", 3840, 2160, None), ("spotlight", 3840, 2160, None), ("house", 3840, 2160, None),
+           ("large", 7680, 4320, 8)]
+THREADS = min(16, os.cpu_count() or 1)
+print("| config | GPUs | rays | kernel ms | Mrays/s | %% FP32 peak (algorithmic) | CPU 1-thread Mrays/s | CPU %d-thread Mrays/s | rows compared | pixels within 1/255 | max abs diff |" % THREADS)
+print("|---|---|---|---|---|---|---|---|---|---|---|")
+for name, w, h, depth in CONFIGS:
+    path = os.path.join(ROOT, "scenes", name + ".gml")
+    call = gmlrt.Program(path=path).calls[0].with_overrides(w, h, depth)
+    depth = call.params.depth
+    flops_per_ray, _ = bench.scene_flops_per_ray(call.blob)
+    scene = gmlrt.DeviceScene(call.blob, 0)
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    for _ in range(12):  # three launches learn the tile hand-out, the rest warm the clocks
+        scene.render_into(call.params, out.data_ptr())
+    sts = [scene.render_into(call.params, out.data_ptr()) for _ in range(5)]
+    ms = sum(s.kernel_ms for s in sts) / len(sts)
+    st = sts[-1]
+    img = out.cpu().numpy()
+    scene.close()
+    step = max(1, h // 24)
+    rows = list(range(step // 2, h, step))
+    prog = oracle_py.OracleProgram(path=path)
+    t0 = time.time()
+    ref, _, cn = prog.render(0, w=w, h=h, depth=depth, y0=rows[0], y1=h, ystep=step, threads=THREADS)
+    tn = time.time() - t0
+    t0 = time.time()
+    _, _, c1 = prog.render(0, w=w, h=h, depth=depth, y0=rows[0], y1=h, ystep=step * 6, threads=1)
+    t1 = time.time() - t0
+    d = np.abs(img[rows].astype(np.int16) - ref.astype(np.int16)).max(axis=-1)
+    tflops = (st.rays * flops_per_ray + st.hits * bench.F_SHADE) / (ms * 1e-3) / 1e12
+    print("| %s %dx%d depth %d | 1 | %d | %.3f | %.0f | %.1f | %.3f | %.2f | %d | %.4f %% | %d |" % (
+        name, w, h, depth, st.rays, ms, st.rays / ms / 1e3, 100.0 * tflops / bench.PEAK_FP32_VALU_TFLOPS,
+        sum(c1.values()) / t1 / 1e6, sum(cn.values()) / tn / 1e6, len(rows), 100.0 * (d <= 1).mean(), int(d.max())), flush=True)
