@@ -61,7 +61,10 @@ class OracleProgram:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module's globals may be gone already
+            pass
 
     @property
     def num_renders(self):
