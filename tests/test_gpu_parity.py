@@ -277,6 +277,24 @@ def test_scene_of_the_independent_restatement(gmlrt, oracle):
     assert np.abs(f64 - ref64).max() <= 1e-9
 
 
+@pytest.mark.parametrize("first", [0, 40, 80])
+def test_random_scenes_match_oracle(gmlrt, oracle, first):
+    # forty seeded random scenes a batch (tests/random_scenes.py): random primitives under random transform chains,
+    # random CSG trees, one to three lights of random kinds, four surface functions; byte-identical images and equal
+    # ray counts against the oracle
+    import random_scenes
+    for seed in range(first, first + 40):
+        text = random_scenes.scene_text(seed)
+        img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+        ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=4)
+        frac1, maxd, ndiff = image_diff(img, ref)
+        assert ndiff == 0, (seed, ndiff, maxd)
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"]), seed
+        both = np.isfinite(f64) & np.isfinite(ref64)
+        assert (np.isfinite(f64) == np.isfinite(ref64)).all(), seed
+        assert np.abs(f64[both] - ref64[both]).max() <= 1e-9, seed
+
+
 # The reference's other scene files (its gml/ directory): every `render` each program executes, at the
 # size and depth the file names.  They exercise what the seven configuration scenes do not: array `get`
 # inside surface functions (checked-cube, cube), closures as values (holes), clampf/frac (golf), several

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Parity fuzz: seeded random scenes (tests/random_scenes.py) at 160x120, depth 4, on the GPU against the CPU oracle;
+prints every seed whose image or ray counts differ.  Usage on the GPU box: python tools/fuzz_parity.py <number of seeds>
+(600 seeds from 1000 on: no difference, the last time it ran)."""
+import sys, os
+ROOT=os.getcwd()
+sys.path.insert(0,'tests'); sys.path.insert(0,'oracle'); sys.path.insert(0,'rust-raytracer_amd')
+import torch, numpy as np, random_scenes, oracle_py, gmlrt
+bad=0
+for seed in range(1000, 1000+int(sys.argv[1])):
+    t = random_scenes.scene_text(seed, 160, 120, 4)
+    try:
+        img, f64, st = gmlrt.render(gmlrt.Program(text=t).calls[0], want_f64=True)
+    except Exception as e:
+        print("seed", seed, "GPU ERR", e, flush=True); bad+=1; continue
+    ref, ref64, cnt = oracle_py.OracleProgram(text=t).render(0, want_f64=True, threads=16)
+    nd = int((img != ref).any(axis=-1).sum())
+    rc = (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    if nd or not rc:
+        bad+=1; print("seed", seed, "differing", nd, "rays equal", rc, flush=True)
+    if seed % 100 == 0: print("at", seed, flush=True)
+print("done, bad =", bad)
