@@ -3,9 +3,15 @@ rules into a random tree (plus a floor), one to three lights of random kinds, a 
 import random
 
 
-def scene_text(seed, width=64, height=48, depth=2):
+def scene_text(seed, width=64, height=48, depth=2, lattice=False):
+    """lattice: positions, sizes and angles come from a coarse grid (halves, right angles), so that faces of
+    different primitives coincide exactly, rays run along axes and spans of zero length appear: the cases in which
+    the order of equal distances and the 1e-10 rule of the CSG sweep decide the picture."""
     rng = random.Random(seed)
-    f = lambda lo, hi: "%.3f" % rng.uniform(lo, hi)
+    if lattice:
+        f = lambda lo, hi: "%.1f" % (round(rng.uniform(lo, hi) * 2.0) / 2.0 or (0.5 if lo > 0 else 0.0))
+    else:
+        f = lambda lo, hi: "%.3f" % rng.uniform(lo, hi)
     out = []
     surfaces = ["{ /v /u /face %s %s %s point %s %s %s } /s%d" % (f(0.1, 1), f(0.1, 1), f(0.1, 1), f(0.3, 1), f(0.0, 0.6), f(1, 8), i)
                 for i in range(2)]
@@ -26,7 +32,7 @@ def scene_text(seed, width=64, height=48, depth=2):
             elif op == "translate":
                 parts.append("%s %s %s translate" % (f(-0.6, 0.6), f(-0.6, 0.6), f(-0.6, 0.6)))
             else:
-                parts.append("%s %s" % (rng.choice(["0.0", "90.0", "180.0", "-90.0", f(-180, 180)]), op))
+                parts.append("%s %s" % (rng.choice(["0.0", "90.0", "180.0", "-90.0"] + ([] if lattice else [f(-180, 180)])), op))
         parts.append("%s %s %s translate" % (f(-1.5, 1.5), f(-1.0, 1.0), f(2.5, 5.0)))
         return " ".join(parts)
 

@@ -277,14 +277,15 @@ def test_scene_of_the_independent_restatement(gmlrt, oracle):
     assert np.abs(f64 - ref64).max() <= 1e-9
 
 
-@pytest.mark.parametrize("first", [0, 40, 80])
-def test_random_scenes_match_oracle(gmlrt, oracle, first):
+@pytest.mark.parametrize("first,lattice", [(0, False), (40, False), (80, False), (0, True), (40, True)])
+def test_random_scenes_match_oracle(gmlrt, oracle, first, lattice):
     # forty seeded random scenes a batch (tests/random_scenes.py): random primitives under random transform chains,
     # random CSG trees, one to three lights of random kinds, four surface functions; byte-identical images and equal
     # ray counts against the oracle
     import random_scenes
     for seed in range(first, first + 40):
-        text = random_scenes.scene_text(seed)
+        # lattice: coinciding faces, rays along axes, zero-length spans (odd image size: a centre row and column)
+        text = random_scenes.scene_text(seed, 65, 49, 2, lattice=True) if lattice else random_scenes.scene_text(seed)
         img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
         ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=4)
         frac1, maxd, ndiff = image_diff(img, ref)
