@@ -1016,8 +1016,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.n_tiles = (uint32_t)n_tiles;
   A.stride = 1;
   static const bool no_stride = std::getenv("GMLRT_IMAGE_ORDER") != nullptr;  // tuning runs
-  if (way == 0 && !s->learn_order && !no_stride && H.n_leaves > 16) {
-    // A handle that renders once knows no tile costs.  In image order the dear tiles of a frame tend to
+  if (way == 0 && !no_stride && H.n_leaves > 16) {
+    // No tile costs known (a handle that renders once, or the first launch of one that will learn them, or a
+    // frame on which neither learnt way paid).  In image order the dear tiles of a frame tend to
     // sit together (the lower rows of a scene on a floor) and the launch ends on them; a golden-ratio
     // stride, made coprime with the tile count, spreads neighbours over the whole launch instead
     // (chess 4K: 7.5 -> 6.4 ms, fractal 2.45 -> 2.15 ms; a scene of a few primitives loses 3 %).
@@ -1093,7 +1094,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       for (int k = 1; k <= 2; k++)
         if (s->order_ms[k] < best) { best = s->order_ms[k]; s->order_way = k; }
       if (std::getenv("GMLRT_VERBOSE"))
-        std::fprintf(stderr, "[gmlrt] tile hand-out: image order %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms -> way %d\n",
+        std::fprintf(stderr, "[gmlrt] tile hand-out: no costs known %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms -> way %d\n",
                      s->order_ms[0], s->order_ms[1], s->order_ms[2], s->order_way);
     }
   } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
