@@ -27,6 +27,27 @@ int fail(int code, const std::string& msg) {
 std::mutex g_mu;
 int g_n_gpus = 0;  // 0 = not initialised
 
+// validate_blob's verdict as a status: malformed, or well-formed but beyond the kernel's limits
+int blob_status(const std::string& v) {
+  if (v.empty()) return GMLRT_OK;
+  return fail(v.rfind("too large:", 0) == 0 ? GMLRT_ERR_SCENE_TOO_LARGE : GMLRT_ERR_BAD_BLOB, v);
+}
+
+// Nothing may leave an extern "C" function as an exception (the derivation of the device programs
+// throws on a program too large for its offsets, any container on allocation failure).
+template <class F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (gmlrt::SceneTooLarge& e) {
+    return fail(GMLRT_ERR_SCENE_TOO_LARGE, e.what());
+  } catch (std::bad_alloc&) {
+    return fail(GMLRT_ERR_SCENE_TOO_LARGE, "out of host memory");
+  } catch (std::exception& e) {
+    return fail(GMLRT_ERR_HIP, e.what());
+  }
+}
+
 }  // namespace
 
 struct gmlrt_scene {
@@ -129,8 +150,8 @@ static int check_params(const gmlrt_params* p) {
 int gmlrt_scene_create(const void* blob, size_t blob_bytes, int device, gmlrt_scene** out) {
   if (!out) return fail(GMLRT_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
-  std::string v = gmlrt::validate_blob(blob, blob_bytes);
-  if (!v.empty()) return fail(GMLRT_ERR_BAD_BLOB, v);
+  return guarded([&]() -> int {
+  if (int rc = blob_status(gmlrt::validate_blob(blob, blob_bytes))) return rc;
   int avail = 0;
   std::string e = gmlrt::dev_count(&avail);
   if (!e.empty() || avail <= 0) return fail(GMLRT_ERR_NO_DEVICE, e.empty() ? "no HIP device visible" : e);
@@ -143,6 +164,7 @@ int gmlrt_scene_create(const void* blob, size_t blob_bytes, int device, gmlrt_sc
   }
   *out = s.release();
   return GMLRT_OK;
+  });
 }
 
 void gmlrt_scene_destroy(gmlrt_scene* s) {
@@ -180,8 +202,7 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
     n_gpus = g_n_gpus;
   }
   if (n_gpus <= 0) return fail(GMLRT_ERR_NOT_INITIALISED, "call gmlrt_init first");
-  std::string v = gmlrt::validate_blob(blob, blob_bytes);
-  if (!v.empty()) return fail(GMLRT_ERR_BAD_BLOB, v);
+  if (int brc = blob_status(gmlrt::validate_blob(blob, blob_bytes))) return brc;
   const auto t0 = std::chrono::steady_clock::now();
   const int64_t w = params->width, h = params->height;
   const int32_t tile_rows = params->tile_rows > 0 ? params->tile_rows : 8;
@@ -336,6 +357,12 @@ static int program_open(const std::string& text, gmlrt_program** out) {
   } catch (gmlrt::UnsupportedSurface& e) {
     rc = GMLRT_ERR_UNSUPPORTED_SURFACE;
     msg = e.what();
+  } catch (gmlrt::SceneTooLarge& e) {
+    rc = GMLRT_ERR_SCENE_TOO_LARGE;
+    msg = e.what();
+  } catch (std::bad_alloc&) {
+    rc = GMLRT_ERR_SCENE_TOO_LARGE;
+    msg = "out of host memory";
   } catch (std::exception& e) {
     rc = GMLRT_ERR_GML;
     msg = e.what();

@@ -959,26 +959,32 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // shading context + one parked record per bounce level + the surface bytecode's registers (at the end)
   const size_t ctx_fields =
       (size_t)kCtxFixed + (size_t)kCtxPerLevel * (size_t)(p.depth + 1) + (size_t)GMLRT_SURF_MAX_REGS;
+  // (the sizes on record are cleared together with the pointers and set again only after every
+  // allocation has succeeded: a failed hipMalloc must not leave sizes that vouch for null buffers)
   if (lanes > s->lanes_alloc || ev_cap > s->ev_slots_alloc) {
+    const size_t l2 = lanes > s->lanes_alloc ? lanes : s->lanes_alloc;
+    const size_t e2 = ev_cap > s->ev_slots_alloc ? ev_cap : s->ev_slots_alloc;
+    const bool more_lanes = l2 > s->lanes_alloc;
     (void)hipFree(s->d_ev_dist);
     (void)hipFree(s->d_ev_meta);
     s->d_ev_dist = s->d_ev_meta = nullptr;
-    const size_t l2 = lanes > s->lanes_alloc ? lanes : s->lanes_alloc;
-    const size_t e2 = ev_cap > s->ev_slots_alloc ? ev_cap : s->ev_slots_alloc;
-    HIP_TRY(hipMalloc(&s->d_ev_dist, l2 * e2 * sizeof(double)));
-    HIP_TRY(hipMalloc(&s->d_ev_meta, l2 * e2 * sizeof(uint32_t)));
-    s->ev_slots_alloc = e2;
-    if (l2 > s->lanes_alloc) {
+    s->ev_slots_alloc = 0;
+    s->lanes_alloc = 0;
+    if (more_lanes) {
       // the context array is laid out per lane too
       (void)hipFree(s->d_ctx);
       s->d_ctx = nullptr;
       s->ctx_fields_alloc = 0;
     }
+    HIP_TRY(hipMalloc(&s->d_ev_dist, l2 * e2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_ev_meta, l2 * e2 * sizeof(uint32_t)));
+    s->ev_slots_alloc = e2;
     s->lanes_alloc = l2;
   }
   if (!s->d_ctx || ctx_fields > s->ctx_fields_alloc) {
     (void)hipFree(s->d_ctx);
     s->d_ctx = nullptr;
+    s->ctx_fields_alloc = 0;
     HIP_TRY(hipMalloc(&s->d_ctx, s->lanes_alloc * ctx_fields * sizeof(double)));
     s->ctx_fields_alloc = ctx_fields;
   }
@@ -996,12 +1002,13 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     (void)hipFree(s->d_tile_batch);
     (void)hipFree(s->d_tile_batch_img);
     s->d_tile_batch = s->d_tile_batch_img = nullptr;
+    s->tiles_alloc = 0;
+    s->order_valid = false;
     HIP_TRY(hipMalloc(&s->d_tile_cost, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_order, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch, (n_tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch_img, (n_tiles + 1) * sizeof(uint32_t)));
     s->tiles_alloc = n_tiles;
-    s->order_valid = false;
   }
   gmlrt_params key = p;
   key.amb[0] = key.amb[1] = key.amb[2] = 0.0;  // the ambient colour moves no ray

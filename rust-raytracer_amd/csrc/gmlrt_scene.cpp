@@ -1010,7 +1010,9 @@ std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc) {
   h.n_code_words = (uint32_t)f.code.size();
   h.n_consts = (uint32_t)f.consts.size();
   h.max_stack = (uint32_t)f.max_stack;
-  if (f.max_events > 0xFFFFFFFFull) throw gml::GmlError("scene too large");
+  if (f.max_events > 0xFFFFFFFFull) throw SceneTooLarge("scene too large");
+  if (2ull * f.leaves.size() > kMaxListEvents) throw SceneTooLarge("a CSG node can yield more than 32767 events per ray");
+  if (lights.size() > kMaxLights) throw SceneTooLarge("more than 2047 lights");
   h.max_events = (uint32_t)f.max_events;
   h.n_bounds = (uint32_t)f.bounds.size();
   std::vector<uint8_t> blob(sizeof(h), 0);
@@ -1035,6 +1037,10 @@ std::string validate_blob(const void* blob, size_t bytes) {
   if (h.version != GMLRT_BLOB_VERSION) return "unsupported blob version";
   if (h.total_bytes != bytes) return "total_bytes does not match the buffer size";
   if (h.n_leaves == 0 || h.n_leaves > (1u << 20)) return "leaf count out of range";
+  // Widths of the kernel's packed per-lane fields (the reference has neither limit): the light a
+  // shadow ray belongs to travels in 11 bits of the lane state, and the length of a list on the
+  // operand stack in 15 bits (a list holds at most two events per leaf below its node).
+  if (h.n_lights > kMaxLights) return "too large: more than 2047 lights";
   if (h.n_bounds > GMLRT_BOUND_MAX + 1u) return "too many bounds";
   if (h.n_nodes != 2 * h.n_leaves - 1 + h.n_bounds) return "node count is not 2*leaves-1+bounds";
   auto section_ok = [&](uint64_t off, uint64_t count, uint64_t elem) {
@@ -1088,6 +1094,7 @@ std::string validate_blob(const void* blob, size_t bytes) {
       if (((w >> 2) & 1u) != (a.first ? 1u : 0u) || ((w >> 3) & 1u) != (b.first ? 1u : 0u))
         return "operator leaf-operand flags do not match the tree";
       max_events = std::max(max_events, sp + a.second + b.second);
+      if (a.second + b.second > kMaxListEvents) return "too large: a CSG node can yield more than 32767 events per ray";
       st.emplace_back(false, a.second + b.second);
     } else if (kind == 2) {
       // the words a bound covers must be exactly one complete subtree: the kernel

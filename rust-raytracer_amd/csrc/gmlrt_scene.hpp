@@ -17,6 +17,14 @@ struct UnsupportedSurface : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+struct SceneTooLarge : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+// Limits of the kernel's packed per-lane fields: lights (11 bits of the lane state) and events in
+// one list of the operand stack (15 bits of its length word).
+constexpr uint32_t kMaxLights = 2047;
+constexpr uint64_t kMaxListEvents = 32767;
+
 // Result of compiling one surface closure (evaluator.rs:776-792 protocol).
 struct SurfaceProgram {
   bool constant = false;           // body never reads face/u/v: consts[0..6) = r g b kd ks n
@@ -51,7 +59,8 @@ void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, do
 // Flattens one render call.  Throws UnsupportedSurface / gml::GmlError.
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc);
 
-// Structural validation of a blob received over the C ABI.  Returns "" if fine.
+// Structural validation of a blob received over the C ABI.  Returns "" if fine; a message that
+// starts with "too large:" means a well-formed scene beyond the kernel's limits.
 std::string validate_blob(const void* blob, size_t bytes);
 
 }  // namespace gmlrt

@@ -131,6 +131,58 @@ def test_blob_validation_rejects_corruption(gmlrt):
     assert b"" != L.gmlrt_last_error()
 
 
+def _blob_with(n_lights=None, n_spheres=None):
+    """A well-formed blob built by hand: a left-deep union of unit spheres (no bounds), constant surfaces."""
+    n_leaves = n_spheres or 1
+    n_lights = n_lights or 0
+    leaf = struct.pack("<12d12dIIII", *([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0] * 2), 0, 0xFFFFFFFF, 0, 0)
+    nodes = [0]
+    for i in range(1, n_leaves):
+        nodes += [i, 0x40000000 | 0 | (4 if i == 1 else 0) | 8]
+    light = struct.pack("<II3d3d3ddd", 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0, 0)
+    consts = struct.pack("<6d", 1, 1, 1, 1, 0, 1)
+    sections = [leaf * n_leaves, struct.pack("<%dI" % len(nodes), *nodes), light * n_lights, b"", consts, b""]
+    hdr_size = 96
+    offs, at, body = [], hdr_size, b""
+    for sec in sections:
+        pad = (-at) % 16
+        body += b"\0" * pad
+        at += pad
+        offs.append(at)
+        body += sec
+        at += len(sec)
+    pad = (-at) % 16
+    body += b"\0" * pad
+    at += pad
+    # max_events: every leaf's two events can sit on the stack when the last merge writes its output above them
+    hdr = struct.pack("<IIQIIIIIIIIQQQQQQ", 0x54524C47, 3, at, n_leaves, len(nodes), n_lights, 0, 6, 2, 4 * n_leaves, 0, *offs)
+    assert len(hdr) == hdr_size
+    return hdr + body
+
+
+def test_blob_validation_enforces_the_kernels_field_widths(gmlrt):
+    # the lane state carries the light index in 11 bits and list lengths in 15: scenes beyond that are
+    # refused with "scene too large", not rendered wrongly (the validator runs before any device is asked for)
+    L = gmlrt.lib()
+    h = ctypes.c_void_p()
+
+    def create(b):
+        return L.gmlrt_scene_create(b, len(b), 0, ctypes.byref(h))
+
+    no_device = -3  # what a well-formed blob gets in a container without a GPU
+    ok = (0, no_device)
+    assert create(_blob_with(n_lights=2047, n_spheres=2)) in ok
+    if h:
+        L.gmlrt_scene_destroy(h)
+    assert create(_blob_with(n_lights=2048, n_spheres=2)) == -8
+    assert b"2047 lights" in L.gmlrt_last_error()
+    assert create(_blob_with(n_spheres=16383)) in ok        # root list: at most 32766 events
+    if h:
+        L.gmlrt_scene_destroy(h)
+    assert create(_blob_with(n_spheres=16384)) == -8        # 32768 would take the flag bit of the length word
+    assert b"32767 events" in L.gmlrt_last_error()
+
+
 def test_write_ppm(gmlrt, tmp_path):
     img = (np.arange(4 * 6 * 3) % 256).astype(np.uint8).reshape(4, 6, 3)
     path = str(tmp_path / "t.ppm")
