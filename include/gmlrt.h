@@ -223,6 +223,21 @@ void gmlrt_scene_destroy(gmlrt_scene* s);
 int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
                         void* hip_stream, gmlrt_stats* stats);
 
+/* gmlrt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments,
+ * same pixels, same ray counts; it calls no hipMalloc / hipFree / hipHostMalloc or any other allocating
+ * routine.  Everything the kernel needs besides the scene handle (created beforehand) and the caller's
+ * output buffers -- per-ray event stacks, shading contexts, counters -- lives in a file-scope __device__
+ * array of GMLRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * As many rays are kept in flight as fit into that array (large CSG trees render slower than through
+ * gmlrt_render_device); a scene of which not even one 256-ray block fits is refused with
+ * GMLRT_ERR_SCENE_TOO_LARGE.  The hand-out order of the pixel tiles is never learnt (that needs tables).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU race, whatever their
+ * streams; the next call clears the counters the previous one left. */
+#define GMLRT_NOALLOC_SCRATCH_BYTES (256u << 20)
+int gmlrt_render_device_noalloc(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
+                                void* hip_stream, gmlrt_stats* stats);
+
 /* The reference's pixel sink, trait Renderer { new_image, push_pixel, done }
  * (raytracer.rs:113-117), which render() obtains from RENDERER_FACTORY
  * (raytracer.rs:183-203, 206-221; the wasm front-end installs a canvas sink through

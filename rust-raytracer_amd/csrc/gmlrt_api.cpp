@@ -173,8 +173,8 @@ void gmlrt_scene_destroy(gmlrt_scene* s) {
   delete s;
 }
 
-int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64, void* hip_stream,
-                        gmlrt_stats* stats) {
+static int render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64, void* hip_stream,
+                         gmlrt_stats* stats, bool no_alloc) {
   if (!s || !d_rgb8) return fail(GMLRT_ERR_INVALID_ARG, "scene or output pointer is NULL");
   int rc = check_params(params);
   if (rc != GMLRT_OK) return rc;
@@ -183,12 +183,24 @@ int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8
   const auto t0 = std::chrono::steady_clock::now();
   gmlrt_stats st;
   std::memset(&st, 0, sizeof(st));
-  std::string e = gmlrt::dev_render(&s->dev, p, d_rgb8, d_rgbf64, hip_stream, &st);
-  if (!e.empty()) return fail(GMLRT_ERR_HIP, e);
-  st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  st.n_gpus = 1;
-  if (stats) *stats = st;
-  return GMLRT_OK;
+  return guarded([&]() -> int {
+    std::string e = gmlrt::dev_render(&s->dev, p, d_rgb8, d_rgbf64, hip_stream, &st, no_alloc);
+    if (!e.empty()) return fail(e.rfind("too large:", 0) == 0 ? GMLRT_ERR_SCENE_TOO_LARGE : GMLRT_ERR_HIP, e);
+    st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.n_gpus = 1;
+    if (stats) *stats = st;
+    return GMLRT_OK;
+  });
+}
+
+int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64, void* hip_stream,
+                        gmlrt_stats* stats) {
+  return render_device(s, params, d_rgb8, d_rgbf64, hip_stream, stats, false);
+}
+
+int gmlrt_render_device_noalloc(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
+                                void* hip_stream, gmlrt_stats* stats) {
+  return render_device(s, params, d_rgb8, d_rgbf64, hip_stream, stats, true);
 }
 
 int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params, uint8_t* rgb8, double* rgbf64,

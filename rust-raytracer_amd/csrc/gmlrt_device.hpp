@@ -70,9 +70,8 @@ struct DeviceScene {
   void* d_ev_meta = nullptr;
   void* d_ctx = nullptr;
   void* d_counters = nullptr;
-  size_t ev_slots_alloc = 0;    // event slots per lane currently allocated
-  size_t ctx_fields_alloc = 0;  // f64 fields per lane currently allocated
-  size_t lanes_alloc = 0;
+  size_t ev_slots_alloc = 0;    // event slots currently allocated (lanes x slots per lane)
+  size_t ctx_fields_alloc = 0;  // f64 context fields currently allocated (lanes x fields per lane)
   // hand-out order of the pixel tiles, learnt from the first launch with a given geometry
   void* d_tile_cost = nullptr;  // u32 per tile, written by every launch
   void* d_tile_order = nullptr; // u32 per tile: tiles sorted by decreasing cost
@@ -94,6 +93,7 @@ struct DeviceScene {
   int dev_cus = 0;              // device facts, asked once: compute units, LDS per block and per unit,
   size_t dev_lds_block = 0, dev_lds_cu = 0;
   int dev_blocks_per_cu = 0;    // resident blocks per unit for this scene's LDS need
+  void* d_static_scratch = nullptr;  // this device's copy of the library's static scratch array (never freed)
   void* ev_start = nullptr;     // hipEvent_t pair used to time the kernel
   void* ev_stop = nullptr;
 };
@@ -104,8 +104,10 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
 void dev_scene_destroy(DeviceScene* s);
 // Launches the render kernel for the partition in `p` and waits for it.
 // d_rgb8 / d_rgbf are device pointers (rgbf may be null).
+// no_alloc: use the library's static scratch array instead of the handle's allocated workspace and make no
+// allocation of any kind (fewer lanes in flight when the array holds fewer; no learnt tile order).
 std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void* d_rgbf, void* stream,
-                       gmlrt_stats* stats);
+                       gmlrt_stats* stats, bool no_alloc = false);
 // Plain device buffers for the host-buffer entry point.
 std::string dev_alloc(int device, size_t bytes, void** out);
 void dev_free(int device, void* p);

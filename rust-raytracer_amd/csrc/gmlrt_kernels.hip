@@ -61,6 +61,7 @@ constexpr uint32_t kClaimCounters = 8, kClaimStride = 4096;
 constexpr size_t kOffDiag = (size_t)kClaimCounters * kClaimStride, kOffShadeArgs = kOffDiag + 256, kOffBlockCounts = kOffDiag + 1024;
 constexpr size_t kMaxGridBlocks = 8192;
 constexpr size_t kCountersBytes = kOffBlockCounts + kMaxGridBlocks * 4 * sizeof(unsigned long long);
+constexpr size_t kNoAllocScratchBytes = GMLRT_NOALLOC_SCRATCH_BYTES;
 constexpr size_t kStagingBytes = 1024 + kMaxGridBlocks * 4 * sizeof(unsigned long long);  // host side: ShadeArgs, then the block counts
 [[maybe_unused]] constexpr int kDiagWaveSlots = 12;  // diagnostic build: counters per wave
 
@@ -691,6 +692,15 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   }
 }
 
+// Scratch of the entry point that allocates nothing (dev_render with no_alloc): claim counters, launch
+// record and per-block ray counts, then the event stacks and the context records of as many lanes as
+// fit.  Every device the library runs on holds its own copy of the array, at its own address; host code
+// never uses the array's name as an address, only what hipGetSymbolAddress returned for that device.
+__device__ __align__(256) uint8_t scratch[kNoAllocScratchBytes];
+std::mutex g_scratch_mu;
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+
 std::string hip_err(const char* what, hipError_t e) {
   return std::string(what) + ": " + hipGetErrorString(e);
 }
@@ -816,6 +826,31 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     HIP_TRY(hipMemcpy(out->d_leaf_surf, leaf_surf.data(), leaf_surf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   if (!out->d_counters) HIP_TRY(hipMalloc(&out->d_counters, kCountersBytes));
+  // through page-locked memory: copies to and from pageable memory are staged and wait
+  if (!out->h_staging) HIP_TRY(hipHostMalloc(&out->h_staging, kStagingBytes, hipHostMallocDefault));
+  if (device < kMaxDevices) {
+    // this device's copy of the static scratch array (once per device, with the device current)
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+      void* ptr = nullptr;
+      HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+      g_scratch_ptr[device] = ptr;
+    }
+    out->d_static_scratch = g_scratch_ptr[device];
+  }
+  {
+    // device facts and the occupancy of this scene's kernel, asked once per handle (the queries cost tens
+    // of microseconds, a fifth of a simple frame; and a render call that must not allocate makes none)
+    const size_t lens_bytes = (((size_t)(out->hdr.max_stack ? out->hdr.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
+    hipDeviceProp_t q;
+    HIP_TRY(hipGetDeviceProperties(&q, device));
+    int b = 1;
+    if (lens_bytes <= 64 * 1024) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true>, kBlock, lens_bytes));
+    out->dev_cus = q.multiProcessorCount;
+    out->dev_lds_block = q.sharedMemPerBlock;
+    out->dev_lds_cu = q.maxSharedMemoryPerMultiProcessor;
+    out->dev_blocks_per_cu = b < 1 ? 1 : b;
+  }
   if (!out->ev_start) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -838,7 +873,7 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.device = s->device;
   spare.d_ev_dist = s->d_ev_dist; spare.d_ev_meta = s->d_ev_meta; spare.d_ctx = s->d_ctx;
   spare.d_counters = s->d_counters;
-  spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc; spare.lanes_alloc = s->lanes_alloc;
+  spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc;
   spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img; spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
@@ -853,7 +888,7 @@ void dev_scene_destroy(DeviceScene* s) {
 }
 
 std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void* d_rgbf, void* stream_v,
-                       gmlrt_stats* stats) {
+                       gmlrt_stats* stats, bool no_alloc) {
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t stream = (hipStream_t)stream_v;
   const gmlrt_blob_header& H = s->hdr;
@@ -907,17 +942,6 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // ---- launch geometry: a persistent grid sized to what the device keeps resident
   const size_t lens_bytes = (((size_t)(H.max_stack ? H.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
   if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
-  // (asked once per handle: the two queries cost tens of microseconds, a fifth of a simple frame)
-  if (s->dev_cus == 0) {
-    hipDeviceProp_t q;
-    HIP_TRY(hipGetDeviceProperties(&q, s->device));
-    int b = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true>, kBlock, lens_bytes));
-    s->dev_cus = q.multiProcessorCount;
-    s->dev_lds_block = q.sharedMemPerBlock;
-    s->dev_lds_cu = q.maxSharedMemoryPerMultiProcessor;
-    s->dev_blocks_per_cu = b < 1 ? 1 : b;
-  }
   struct { int multiProcessorCount; size_t sharedMemPerBlock, maxSharedMemoryPerMultiProcessor; } prop = {
       s->dev_cus, s->dev_lds_block, s->dev_lds_cu};
   const int blocks_per_cu = s->dev_blocks_per_cu;
@@ -954,48 +978,59 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (grid < 1) grid = 1;
 
   // ---- workspace
-  const size_t lanes = (size_t)grid * kBlock;
   const size_t ev_cap = H.max_events < 2 ? 2 : H.max_events;
   // shading context + one parked record per bounce level + the surface bytecode's registers (at the end)
   const size_t ctx_fields =
       (size_t)kCtxFixed + (size_t)kCtxPerLevel * (size_t)(p.depth + 1) + (size_t)GMLRT_SURF_MAX_REGS;
-  // (the sizes on record are cleared together with the pointers and set again only after every
-  // allocation has succeeded: a failed hipMalloc must not leave sizes that vouch for null buffers)
-  if (lanes > s->lanes_alloc || ev_cap > s->ev_slots_alloc) {
-    const size_t l2 = lanes > s->lanes_alloc ? lanes : s->lanes_alloc;
-    const size_t e2 = ev_cap > s->ev_slots_alloc ? ev_cap : s->ev_slots_alloc;
-    const bool more_lanes = l2 > s->lanes_alloc;
+  uint8_t* d_counters = (uint8_t*)s->d_counters;
+  if (no_alloc) {
+    // Everything the kernel writes besides its outputs comes out of this device's copy of the static array:
+    // counters | event distances | context records | event meta words.  The grid shrinks to the lanes that fit.
+    uint8_t* base_ptr = (uint8_t*)s->d_static_scratch;
+    if (!base_ptr) return "too large: no static scratch on this device";
+    constexpr size_t counters_bytes = (kCountersBytes + 255) & ~(size_t)255;
+    const size_t per_lane = ev_cap * (sizeof(double) + sizeof(uint32_t)) + ctx_fields * sizeof(double);
+    const uint64_t fit = (kNoAllocScratchBytes - counters_bytes) / (per_lane * kBlock);
+    if (fit < 1) return "too large: one block of this scene needs more than the static scratch buffer holds";
+    if (grid > fit) grid = fit;
+    const size_t lanes_na = (size_t)grid * kBlock;
+    d_counters = base_ptr;
+    A.ev_dist = (double*)(base_ptr + counters_bytes);
+    A.ctx = (double*)(base_ptr + counters_bytes + lanes_na * ev_cap * sizeof(double));
+    A.ev_meta = (uint32_t*)(base_ptr + counters_bytes + lanes_na * (ev_cap + ctx_fields) * sizeof(double));
+    A.ev_cap = (uint32_t)ev_cap;
+    A.ctx_fields = (uint32_t)ctx_fields;
+  } else {
+  // (a size on record is cleared together with its pointer and set again only after the allocation
+  // has succeeded: a failed hipMalloc must not leave a size that vouches for a null buffer)
+  const size_t lanes = (size_t)grid * kBlock;
+  if (lanes * ev_cap > s->ev_slots_alloc) {
     (void)hipFree(s->d_ev_dist);
     (void)hipFree(s->d_ev_meta);
     s->d_ev_dist = s->d_ev_meta = nullptr;
     s->ev_slots_alloc = 0;
-    s->lanes_alloc = 0;
-    if (more_lanes) {
-      // the context array is laid out per lane too
-      (void)hipFree(s->d_ctx);
-      s->d_ctx = nullptr;
-      s->ctx_fields_alloc = 0;
-    }
-    HIP_TRY(hipMalloc(&s->d_ev_dist, l2 * e2 * sizeof(double)));
-    HIP_TRY(hipMalloc(&s->d_ev_meta, l2 * e2 * sizeof(uint32_t)));
-    s->ev_slots_alloc = e2;
-    s->lanes_alloc = l2;
+    HIP_TRY(hipMalloc(&s->d_ev_dist, lanes * ev_cap * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_ev_meta, lanes * ev_cap * sizeof(uint32_t)));
+    s->ev_slots_alloc = lanes * ev_cap;
   }
-  if (!s->d_ctx || ctx_fields > s->ctx_fields_alloc) {
+  if (lanes * ctx_fields > s->ctx_fields_alloc) {
     (void)hipFree(s->d_ctx);
     s->d_ctx = nullptr;
     s->ctx_fields_alloc = 0;
-    HIP_TRY(hipMalloc(&s->d_ctx, s->lanes_alloc * ctx_fields * sizeof(double)));
-    s->ctx_fields_alloc = ctx_fields;
+    HIP_TRY(hipMalloc(&s->d_ctx, lanes * ctx_fields * sizeof(double)));
+    s->ctx_fields_alloc = lanes * ctx_fields;
   }
   A.ev_dist = (double*)s->d_ev_dist;
   A.ev_meta = (uint32_t*)s->d_ev_meta;
-  A.ev_cap = (uint32_t)s->ev_slots_alloc;
+  A.ev_cap = (uint32_t)ev_cap;
   A.ctx = (double*)s->d_ctx;
-  A.ctx_fields = (uint32_t)s->ctx_fields_alloc;
+  A.ctx_fields = (uint32_t)ctx_fields;
+  }
+  const size_t lanes = (size_t)grid * kBlock;
+  (void)lanes;
   // ---- tile order: costs of an earlier launch with the same geometry, dearest first
   const size_t n_tiles = (size_t)(n_slots / 64);
-  if (n_tiles > s->tiles_alloc) {
+  if (!no_alloc && n_tiles > s->tiles_alloc) {
     (void)hipFree(s->d_tile_cost);
     (void)hipFree(s->d_tile_order);
     s->d_tile_cost = s->d_tile_order = nullptr;
@@ -1013,9 +1048,13 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   gmlrt_params key = p;
   key.amb[0] = key.amb[1] = key.amb[2] = 0.0;  // the ambient colour moves no ray
   key.tile_rows = A.tile_rows; key.part = A.part; key.nparts = A.nparts; key.reserved = 0;
-  if (s->order_valid && std::memcmp(&key, &s->order_key, sizeof(key)) != 0) s->order_valid = false;
-  if (!s->order_valid) s->order_state = 0;
-  static const bool no_order = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
+  if (!no_alloc) {
+    if (s->order_valid && std::memcmp(&key, &s->order_key, sizeof(key)) != 0) s->order_valid = false;
+    if (!s->order_valid) s->order_state = 0;
+  }
+  static const bool no_order_env = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
+  // (a call that must not allocate neither learns a hand-out order nor uses one: the tables are allocations)
+  const bool no_order = no_order_env || no_alloc;
   const int way = !s->order_valid || no_order ? 0 : s->order_state == 1 ? 1 : s->order_state == 2 ? 2 : s->order_state == 3 ? s->order_way : 0;
   const bool ordered = way == 1;
   A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
@@ -1042,11 +1081,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(d_tile_dbg, 0, n_tiles * 4 * sizeof(unsigned long long), stream));
   A.tile_dbg = d_tile_dbg;
 #endif
-  A.next_batch = (unsigned int*)s->d_counters;
-  A.block_counts = (unsigned long long*)((uint8_t*)s->d_counters + kOffBlockCounts);
-  A.diag = (unsigned long long*)((uint8_t*)s->d_counters + kOffDiag);
+  A.next_batch = (unsigned int*)d_counters;
+  A.block_counts = (unsigned long long*)(d_counters + kOffBlockCounts);
+  A.diag = (unsigned long long*)(d_counters + kOffDiag);
 
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, kOffShadeArgs, stream));  // claim and diagnostic counters; every block writes its counts
+  // (with the static scratch this clears what the previous call on this device left in the counters)
+  HIP_TRY(hipMemsetAsync(d_counters, 0, kOffShadeArgs, stream));  // claim and diagnostic counters; every block writes its counts
   ShadeArgs SA;
   std::memset(&SA, 0, sizeof(SA));
   for (int i = 0; i < 3; i++) SA.amb[i] = p.amb[i];
@@ -1069,21 +1109,19 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long), stream));
   SA.diag_waves = d_diag_waves;
 #endif
-  // through page-locked memory: copies to and from pageable memory are staged and wait
-  if (!s->h_staging) HIP_TRY(hipHostMalloc(&s->h_staging, kStagingBytes, hipHostMallocDefault));
   std::memcpy(s->h_staging, &SA, sizeof(SA));
-  HIP_TRY(hipMemcpyAsync((uint8_t*)s->d_counters + kOffShadeArgs, s->h_staging, sizeof(SA), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, sizeof(SA), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   if (A.lds_ctx)
     hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + kOffShadeArgs), A);
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   else
     hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
-                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)((uint8_t*)s->d_counters + kOffShadeArgs), A);
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   const unsigned long long* per_block = (const unsigned long long*)((uint8_t*)s->h_staging + 1024);
-  HIP_TRY(hipMemcpyAsync((void*)per_block, (uint8_t*)s->d_counters + kOffBlockCounts, (size_t)grid * 4 * sizeof(unsigned long long),
+  HIP_TRY(hipMemcpyAsync((void*)per_block, d_counters + kOffBlockCounts, (size_t)grid * 4 * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   unsigned long long counts[4] = {0, 0, 0, 0};
@@ -1091,7 +1129,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     for (int k = 0; k < 4; k++) counts[k] += per_block[b * 4 + k];
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
-  if ((s->order_state == 1 || s->order_state == 2) && way == s->order_state) {
+  if (no_alloc) {
+    // nothing to learn and nothing to record
+  } else if ((s->order_state == 1 || s->order_state == 2) && way == s->order_state) {
     // a trial: the learnt order trades cache locality between neighbouring waves for a shorter tail (scenes
     // with evenly priced tiles lose); the batch table over the image order only saves atomics
     s->order_ms[way] = ms;

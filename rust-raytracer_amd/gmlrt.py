@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GMLRT_LIB") or os.path.join(_HERE, "libgmlrt.so")  # 
 EXPORTS = [
     "gmlrt_strerror", "gmlrt_last_error", "gmlrt_part_rows", "gmlrt_part_row_index", "gmlrt_init",
     "gmlrt_shutdown", "gmlrt_device_count", "gmlrt_render", "gmlrt_scene_create", "gmlrt_scene_destroy",
-    "gmlrt_render_device", "gmlrt_render_to_sink", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
+    "gmlrt_render_device", "gmlrt_render_device_noalloc", "gmlrt_render_to_sink", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
     "gmlrt_program_close", "gmlrt_program_num_renders", "gmlrt_program_render_call",
 ]
 
@@ -99,6 +99,7 @@ def lib():
         L.gmlrt_scene_destroy.argtypes = [vp]
         L.gmlrt_scene_destroy.restype = None
         L.gmlrt_render_device.argtypes = [vp, ctypes.POINTER(Params), vp, vp, vp, ctypes.POINTER(Stats)]
+        L.gmlrt_render_device_noalloc.argtypes = L.gmlrt_render_device.argtypes
         L.gmlrt_write_ppm.argtypes = [ctypes.c_char_p, vp, ctypes.c_int64, ctypes.c_int64]
         L.gmlrt_program_open_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
         L.gmlrt_program_open_text.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -217,10 +218,12 @@ class DeviceScene:
         self._blob = blob
         _check(lib().gmlrt_scene_create(blob, len(blob), device, ctypes.byref(self.h)), "gmlrt_scene_create")
 
-    def render_into(self, params, d_rgb8_ptr, d_f64_ptr=None, stream=None):
+    def render_into(self, params, d_rgb8_ptr, d_f64_ptr=None, stream=None, no_alloc=False):
+        """gmlrt_render_device, or with no_alloc its variant that allocates nothing (static scratch array)."""
         st = Stats()
-        _check(lib().gmlrt_render_device(self.h, ctypes.byref(params), d_rgb8_ptr, d_f64_ptr, stream,
-                                         ctypes.byref(st)), "gmlrt_render_device")
+        fn = lib().gmlrt_render_device_noalloc if no_alloc else lib().gmlrt_render_device
+        _check(fn(self.h, ctypes.byref(params), d_rgb8_ptr, d_f64_ptr, stream, ctypes.byref(st)),
+               "gmlrt_render_device_noalloc" if no_alloc else "gmlrt_render_device")
         return st
 
     def close(self):
