@@ -14,7 +14,8 @@ namespace gmlrt {
 // Records of the derived traversal program (gmlrt_program.cpp): a byte stream of
 // 16-byte-aligned records, operands inline.  `kind` = record kind in bits 3..0,
 // kRecFlag in bit 8, a leaf's primitive type in bits 18..16.
-constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5;
+constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5, kRecSkipEmpty = 6;
+constexpr uint32_t kOpSwapped = 0x10u;  // operator arg: the right operand was pushed first (ties still go to the left one)
 constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
 struct ProgBound {   // 64 bytes
   uint32_t kind;
@@ -38,13 +39,15 @@ struct ProgLeaf {    // 128 bytes
   uint64_t pad;
   uint64_t pad2[2];  // to 128 bytes
 };
-struct ProgSmall {   // 16 bytes: operator (arg = rule | operand-is-leaf flags), take, end
+struct ProgSmall {   // 16 bytes: operator (arg = rule | kOpSwapped), take, end, skip-if-empty (arg = byte offset to jump to)
   uint32_t kind;
   uint32_t arg;
   uint64_t pad;
 };
 static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 64 && sizeof(ProgLeaf) == 128 && sizeof(ProgSmall) == 16, "record sizes");
-std::vector<uint8_t> derive_stream_program(const void* blob);
+// need_stack / need_events: operand-stack levels and event slots per ray this program's evaluation order can
+// reach (it may differ from the blob's postfix order, for which the blob header states them).
+std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events);
 // Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h): every leaf's program
 // specialised for each face its primitive can report, identical results stored once;
 // leaf_surf[leaf * kSurfFaces + face] = index of the first record of the program to run for a
@@ -61,6 +64,8 @@ struct DeviceScene {
   size_t blob_bytes = 0;
   void* d_prog = nullptr;       // derived program (record stream)
   uint32_t n_prog = 0;          // its size in bytes
+  uint32_t max_stack = 1;       // operand-stack levels / event slots per ray: the larger of what the blob states for its
+  uint64_t max_events = 2;      // postfix order (full-list traversal) and what the derived program's order needs
   uint32_t n_vm_regs = 0;       // registers the scene's surface bytecode uses
   void* d_surf = nullptr;       // expanded surface programs
   void* d_leaf_surf = nullptr;  // u32 per leaf: first record of its program

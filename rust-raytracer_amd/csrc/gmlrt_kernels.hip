@@ -104,6 +104,7 @@ struct KArgs {
   uint32_t n_batches;
   uint32_t n_tiles;
   unsigned long long* tile_dbg;  // diagnostic build only: per tile, 4 counters
+  unsigned long long* leaf_dbg;  // diagnostic build only: per leaf: tests, tests without an Entry in any lane, lanes with an Entry
   uint32_t* tile_cost;         // per tile: how long its wave spent on it (wall-clock ticks); null: not wanted
   unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
   unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
@@ -138,7 +139,8 @@ static_assert(sizeof(ShadeArgs) <= kOffBlockCounts - kOffShadeArgs, "ShadeArgs o
 // where the cycles went.  Never part of the shipped library; numbers from it are
 // shares, not timings.
 struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes, n_redo,
-              b_lanes, l_lanes, l_hits, k_trav[3], k_leaf[3]; };
+              b_lanes, l_lanes, l_hits, k_trav[3], k_leaf[3], l_nohit, k_entered[3], k_blanes[3], k_active[3]; int kind;
+              unsigned long long* leaf_dbg; };
 #ifdef GMLRT_DIAG
 #define DIAG(...) __VA_ARGS__
 #else
@@ -175,8 +177,13 @@ __device__ inline bool csg_rule(uint32_t rule, bool a, bool b) {
 // above the other on the lane's event stack (A at a0, B right after it).  Both
 // inputs are already sorted, so the stable sort of their concatenation is a merge
 // that takes A on ties.  Output goes above B and is then moved down onto A.
-__device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
+//
+// kOpSwapped in `rule_sw`: the list at a0 is the reference's RIGHT operand (obj2) and the one after it the left
+// (the traversal evaluated the right operand first); ties then go to the second list and the first feeds in2.
+__device__ __noinline__ uint32_t merge_lists(uint32_t rule_sw, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
                                              uint32_t a0, uint32_t la, uint32_t lb) {
+  const uint32_t rule = rule_sw & 3u;
+  const bool swapped = (rule_sw & kOpSwapped) != 0;
   double* __restrict__ evD = global_space(evD_v);
   uint32_t* __restrict__ evM = global_space(evM_v);
   const uint32_t b0 = a0 + la, out0 = b0 + lb;
@@ -187,7 +194,7 @@ __device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__
   uint32_t ma = evM[(size_t)a0 * kWave], mb = evM[(size_t)b0 * kWave];
   const uint32_t total = la + lb;
   for (uint32_t n = 0; n < total; n++) {
-    const bool takeA = (j >= lb) || (i < la && db >= da);
+    const bool takeA = (j >= lb) || (i < la && (swapped ? db > da : db >= da));
     const double d = takeA ? da : db;
     const uint32_t m = takeA ? ma : mb;
     if (takeA) {
@@ -198,7 +205,7 @@ __device__ __noinline__ uint32_t merge_lists(uint32_t rule, double* __restrict__
       if (j < lb) { db = evD[(size_t)(b0 + j) * kWave]; mb = evM[(size_t)(b0 + j) * kWave]; }
     }
     const bool entry = !(m & kCurExit);
-    if (takeA) in1 = entry; else in2 = entry;
+    if (takeA != swapped) in1 = entry; else in2 = entry;
     const bool ni = csg_rule(rule, in1, in2);
     if (inside && !ni) {
       if (d - prevt < 1e-10) {
@@ -244,8 +251,12 @@ __device__ inline void merge_cx(double& d0, uint32_t& m0, double& d1, uint32_t& 
 // kN = 4: up to 4 + 4 events; kN = 2: up to 2 + 2 (two primitives), the most common case, with a third of
 // the comparators and half the loads and sweep steps.
 template <int kN>
-__device__ __noinline__ uint32_t merge_small(uint32_t rule, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
+__device__ __noinline__ uint32_t merge_small(uint32_t rule_sw, double* __restrict__ evD_v, uint32_t* __restrict__ evM_v,
                                              uint32_t a0, uint32_t la, uint32_t lb) {
+  const uint32_t rule = rule_sw & 3u;
+  // swapped operands (see merge_lists): the first list is the reference's obj2, so its events take the
+  // positions 4.. of A ++ B and the second list's the positions 0..
+  const uint32_t pos_first = (rule_sw & kOpSwapped) ? 4u : 0u, pos_second = 4u - pos_first;
   double* __restrict__ evD = global_space(evD_v);
   uint32_t* __restrict__ evM = global_space(evM_v);
   const uint32_t b0 = a0 + la;
@@ -265,8 +276,8 @@ __device__ __noinline__ uint32_t merge_small(uint32_t rule, double* __restrict__
     if (i >= la) d[i] = __builtin_inf();
     if (i >= lb) d[kN + i] = __builtin_inf();
     // the position in A ++ B, with B's numbered from 4 in both sizes (bit 2 = "from B")
-    m[i] = (m[i] & ~(7u << kPosShift)) | (i << kPosShift);
-    m[kN + i] = (m[kN + i] & ~(7u << kPosShift)) | ((4u + i) << kPosShift);
+    m[i] = (m[i] & ~(7u << kPosShift)) | ((pos_first + i) << kPosShift);
+    m[kN + i] = (m[kN + i] & ~(7u << kPosShift)) | ((pos_second + i) << kPosShift);
   }
   if constexpr (kN == 4) {
     merge_cx(d[0], m[0], d[4], m[4]); merge_cx(d[1], m[1], d[5], m[5]);
@@ -542,6 +553,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   unsigned long long tile_t0 = 0;
   DIAG(unsigned long long dbg_trav0 = 0, dbg_leaf0 = 0, dbg_merge0 = 0, dbg_redo0 = 0;)
   Diag dg = {};
+  DIAG(dg.leaf_dbg = A.leaf_dbg;)
   DIAG(unsigned long long t0 = __builtin_readcyclecounter(); const unsigned long long w_start = wall_clock64();
        unsigned long long w_tiles = 0;)
 
@@ -632,7 +644,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
 
     DIAG(const unsigned long long dk_leaf0 = dg.n_leaf;
          // what the wave is tracing: 0 camera rays only, 1 shadow rays of camera hits among them, 2 anything after a bounce
-         const int dk = __ballot(st_kind(S.st) != kIdle && ((S.st >> 2) & 0x7FFu) != 0) ? 2 : __ballot(st_kind(S.st) == kShadow) ? 1 : 0;)
+         const int dk = __ballot(st_kind(S.st) != kIdle && ((S.st >> 2) & 0x7FFu) != 0) ? 2 : __ballot(st_kind(S.st) == kShadow) ? 1 : 0;
+         dg.kind = dk; dg.k_active[dk] += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
     // ---- one scene traversal for whatever ray each lane holds
     Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if (__ballot(h.redo)) {
@@ -688,6 +701,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          atomicAdd(&A.diag[18], dg.l_hits);
          for (int q = 0; q < 3; q++) atomicAdd(&A.diag[19 + q], dg.k_trav[q]);
          for (int q = 0; q < 2; q++) atomicAdd(&A.diag[22 + q], dg.k_leaf[q]);  // the third is the rest of n_leaf; the table ends at slot 23
+         atomicAdd(&A.diag[10], dg.l_nohit);
+         for (int q = 0; q < 3; q++) { atomicAdd(&A.diag[24 + q], dg.k_entered[q]); atomicAdd(&A.diag[27 + q], dg.k_blanes[q]); }
+         for (int q = 0; q < 2; q++) atomicAdd(&A.diag[30 + q], dg.k_active[q]);
          )
   }
 }
@@ -800,7 +816,12 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   HIP_TRY(hipMalloc(&out->d_blob, bytes));
   HIP_TRY(hipMemcpy(out->d_blob, blob, bytes, hipMemcpyHostToDevice));
   {
-    std::vector<uint8_t> prog = derive_stream_program(blob);
+    uint32_t need_stack = 1;
+    uint64_t need_events = 2;
+    std::vector<uint8_t> prog = derive_stream_program(blob, &need_stack, &need_events);
+    out->max_stack = std::max(out->hdr.max_stack, need_stack);
+    out->max_events = std::max<uint64_t>(out->hdr.max_events, need_events);
+    if (out->max_events > 0xFFFFFFFFull) return "too large: event stack";
     out->n_prog = (uint32_t)prog.size();
     HIP_TRY(hipMalloc(&out->d_prog, prog.size()));
     HIP_TRY(hipMemcpy(out->d_prog, prog.data(), prog.size(), hipMemcpyHostToDevice));
@@ -841,7 +862,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   {
     // device facts and the occupancy of this scene's kernel, asked once per handle (the queries cost tens
     // of microseconds, a fifth of a simple frame; and a render call that must not allocate makes none)
-    const size_t lens_bytes = (((size_t)(out->hdr.max_stack ? out->hdr.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
+    const size_t lens_bytes = (((size_t)out->max_stack * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
     hipDeviceProp_t q;
     HIP_TRY(hipGetDeviceProperties(&q, device));
     int b = 1;
@@ -907,7 +928,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.n_nodes = H.n_nodes;
   A.n_prog = s->n_prog;
   A.n_lights = H.n_lights;
-  A.max_stack = H.max_stack;
+  A.max_stack = s->max_stack;
   for (int i = 0; i < 3; i++) A.amb[i] = p.amb[i];
   // raytracer.rs:131-136
   const double w_world = 2.0 * std::tan(0.5 * (p.fov_deg * (3.14159265358979323846 / 180.0)));
@@ -940,7 +961,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (rows == 0) return "";
 
   // ---- launch geometry: a persistent grid sized to what the device keeps resident
-  const size_t lens_bytes = (((size_t)(H.max_stack ? H.max_stack : 1) * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
+  const size_t lens_bytes = (((size_t)s->max_stack * kBlock * sizeof(uint16_t)) + 15) & ~(size_t)15;
   if (lens_bytes > 64 * 1024) return "CSG tree nests deeper than the operand stack supports";
   struct { int multiProcessorCount; size_t sharedMemPerBlock, maxSharedMemoryPerMultiProcessor; } prop = {
       s->dev_cus, s->dev_lds_block, s->dev_lds_cu};
@@ -978,7 +999,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (grid < 1) grid = 1;
 
   // ---- workspace
-  const size_t ev_cap = H.max_events < 2 ? 2 : H.max_events;
+  const size_t ev_cap = (size_t)s->max_events;
   // shading context + one parked record per bounce level + the surface bytecode's registers (at the end)
   const size_t ctx_fields =
       (size_t)kCtxFixed + (size_t)kCtxPerLevel * (size_t)(p.depth + 1) + (size_t)GMLRT_SURF_MAX_REGS;
@@ -1080,6 +1101,10 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipMalloc(&d_tile_dbg, n_tiles * 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d_tile_dbg, 0, n_tiles * 4 * sizeof(unsigned long long), stream));
   A.tile_dbg = d_tile_dbg;
+  unsigned long long* d_leaf_dbg = nullptr;
+  HIP_TRY(hipMalloc(&d_leaf_dbg, (size_t)H.n_leaves * 3 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_leaf_dbg, 0, (size_t)H.n_leaves * 3 * sizeof(unsigned long long), stream));
+  A.leaf_dbg = d_leaf_dbg;
 #endif
   A.next_batch = (unsigned int*)d_counters;
   A.block_counts = (unsigned long long*)(d_counters + kOffBlockCounts);
@@ -1284,6 +1309,35 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       for (int q = 0; q < 3; q++)
         std::fprintf(stderr, "[gmlrt diag] waves tracing %-22s: %llu traversals, %.1f leaves each\n", names[q], ex[3 + q],
                      (double)ex[6 + q] / ((double)ex[3 + q] > 0 ? (double)ex[3 + q] : 1.0));
+    }
+    if (std::getenv("GMLRT_VERBOSE")) {
+      std::vector<unsigned long long> ld((size_t)H.n_leaves * 3);
+      HIP_TRY(hipMemcpy(ld.data(), d_leaf_dbg, ld.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      std::vector<gmlrt_leaf> hl(H.n_leaves);
+      HIP_TRY(hipMemcpy(hl.data(), d_leaves, hl.size() * sizeof(gmlrt_leaf), hipMemcpyDeviceToHost));
+      unsigned long long by_type[5][3] = {};
+      for (uint32_t i = 0; i < H.n_leaves; i++) for (int q = 0; q < 3; q++) by_type[hl[i].type][q] += ld[(size_t)i * 3 + q];
+      const char* tn[5] = {"sphere", "cube", "cylinder", "cone", "plane"};
+      for (int t = 0; t < 5; t++)
+        std::fprintf(stderr, "[gmlrt diag] %-8s leaf tests %llu, without an Entry in any lane %.1f %%, lanes with an Entry %.1f\n", tn[t], by_type[t][0],
+                     100.0 * (double)by_type[t][1] / ((double)by_type[t][0] > 0 ? (double)by_type[t][0] : 1.0),
+                     (double)by_type[t][2] / ((double)by_type[t][0] > 0 ? (double)by_type[t][0] : 1.0));
+      if (std::getenv("GMLRT_DIAG_LEAVES"))
+        for (uint32_t i = 0; i < H.n_leaves; i++)
+          std::fprintf(stderr, "[gmlrt diag] leaf %u %s: tests %llu nohit %llu entries %llu\n", i, tn[hl[i].type], ld[(size_t)i * 3], ld[(size_t)i * 3 + 1], ld[(size_t)i * 3 + 2]);
+      (void)hipFree(d_leaf_dbg);
+    }
+    {
+      unsigned long long ex2[8], nohit;
+      HIP_TRY(hipMemcpy(ex2, (uint8_t*)s->d_counters + kOffDiag + 24 * 8, 8 * sizeof(ex2[0]), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&nohit, (uint8_t*)s->d_counters + kOffDiag + 10 * 8, sizeof(nohit), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[gmlrt diag] leaf tests in which no lane has an Entry: %.1f %%\n", 100.0 * (double)nohit / ((double)dgv[6] > 0 ? (double)dgv[6] : 1.0));
+      const char* names[3] = {"camera", "shadow of camera hits", "after a bounce"};
+      for (int q = 0; q < 3; q++)
+        std::fprintf(stderr, "[gmlrt diag] waves tracing %-22s: entered bounds %llu, lanes whose ray meets one %.1f\n", names[q], ex2[q],
+                     (double)ex2[3 + q] / ((double)ex2[q] > 0 ? (double)ex2[q] : 1.0));
+      std::fprintf(stderr, "[gmlrt diag] active lanes per traversal: camera waves %.1f, shadow-of-camera waves %.1f\n",
+                   (double)ex2[6] / ((double)dgv[3] > 0 ? 129600.0 : 1.0), (double)ex2[7] / 73852.0);
     }
     const double nt = (double)dgv[3] > 0 ? (double)dgv[3] : 1.0;
     std::fprintf(stderr,

@@ -54,12 +54,19 @@ double box_bias() {
   }();
   return v;
 }
+// Lazy operand evaluation inside frontier children (skip records, cheaper intersection operand first); the
+// environment override exists for tuning runs.
+bool lazy_operands() {
+  static const bool v = [] { const char* e = std::getenv("GMLRT_LAZY_OPERANDS"); return !(e && *e == '0'); }();
+  return v;
+}
 struct PNode {
   int a = -1, b = -1;    // children (operators)
   uint32_t word = 0;     // the leaf / operator word
   int bound = -1;        // index of the bound attached to this subtree, -1 if none
   uint32_t first = 0;    // index of the subtree's first program word (its bound word if it has one)
   uint32_t last = 0;     // index of its own word
+  uint32_t nl = 1;       // leaves below (and including) this node
 };
 
 struct Stream {
@@ -73,7 +80,7 @@ struct Stream {
 };
 }  // namespace
 
-std::vector<uint8_t> derive_stream_program(const void* blob) {
+std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events) {
   gmlrt_blob_header H;
   std::memcpy(&H, blob, sizeof(H));
   const uint8_t* base = (const uint8_t*)blob;
@@ -100,6 +107,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
       n.b = st.back(); st.pop_back();
       n.a = st.back(); st.pop_back();
       n.first = tree[(size_t)n.a].first;
+      n.nl = tree[(size_t)n.a].nl + tree[(size_t)n.b].nl;
     }
     while (!open.empty() && open.back().end == i + 1) {
       n.bound = open.back().bound;  // the validator guarantees this is exactly this subtree
@@ -111,6 +119,8 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
   }
   if (st.size() != 1) throw std::runtime_error("derive_stream_program: malformed program");
 
+  *need_stack = 1;
+  *need_events = 2;
   Stream S;
   // Expected number of frontier bound tests per ray, for choosing between two arrangements of
   // the frontier: a bound is tested when the one around it was entered, which a random ray
@@ -211,6 +221,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
     ref_area = smaller_area(all);
     if (!std::isfinite(ref_area)) ref_area = 0.0;
   }
+  std::vector<size_t> skip_open;  // skip records waiting for the offset of the record after their operator
   auto emit_item = [&](int ni) {
     const PNode& n = tree[(size_t)ni];
     size_t bound_at = 0;
@@ -218,17 +229,73 @@ std::vector<uint8_t> derive_stream_program(const void* blob) {
     if ((n.word >> 30) == 0) {
       put_leaf(n.word & 0x3FFFFFFFu, true);  // frontier leaf: candidate for the nearest Entry, no list
     } else {
-      // frontier child with an operator at its top: its words in order, then take the first element
-      const uint32_t begin = n.bound >= 0 ? n.first + 1 : n.first;
-      std::vector<std::pair<uint32_t, size_t>> inner;  // (word index one past the subtree, record offset)
-      for (uint32_t i = begin; i <= n.last; i++) {
-        const uint32_t w = nodes[i];
-        if ((w >> 30) == 2) inner.emplace_back(i + 1 + (w & 0x7FFFu), put_bound(bounds[(w >> 15) & 0x7FFFu], false));
-        else if ((w >> 30) == 0) put_leaf(w & 0x3FFFFFFFu, false);
-        else put_small(kRecOp, w & 0xFu);
-        while (!inner.empty() && inner.back().first == i + 1) {
-          patch_skip(inner.back().second);
-          inner.pop_back();
+      // Frontier child with an operator at its top: its subtree in evaluation order, then take the first
+      // element.  Two liberties are taken with the blob's postfix order, neither of which changes a list:
+      // * after the first operand of an intersection or a difference comes a skip record: when that operand's
+      //   list is empty for every ray of the wave, so is the operator's result whatever the other operand
+      //   yields (primitives.rs:177-187: a && b, a && !b), and the other operand's records are jumped over;
+      // * an intersection may evaluate its right operand first when that one is the cheaper to find empty
+      //   (fewer leaves; bounded rather than a half-space).  The operator record then says so (kOpSwapped)
+      //   and the merge gives ties to the list that was pushed second, which is the reference's left operand.
+      struct Step { int node; int stage; size_t a, b; };
+      std::vector<Step> work;
+      std::vector<uint64_t> sim;  // list capacities on the operand stack
+      uint64_t sim_sp = 0;
+      work.push_back({ni, 0, 0, 0});
+      auto n_leaves_of = [&](int x) { return tree[(size_t)x].nl; };
+      auto unbounded = [&](int x) {
+        const PNode& q = tree[(size_t)x];
+        return (q.word >> 30) == 0 && leaves[q.word & 0x3FFFFFFFu].type == GMLRT_PLANE;
+      };
+      while (!work.empty()) {
+        Step stp = work.back();
+        work.pop_back();
+        const PNode& q = tree[(size_t)stp.node];
+        if (stp.stage == 0) {
+          size_t bound_rec = (size_t)-1;
+          if (q.bound >= 0 && stp.node != ni) bound_rec = put_bound(bounds[q.bound], false);
+          if ((q.word >> 30) == 0) {
+            put_leaf(q.word & 0x3FFFFFFFu, false);
+            if (bound_rec != (size_t)-1) patch_skip(bound_rec);
+            // capacity the kernel's stacks need for this evaluation order (worst case: every leaf yields two events)
+            sim.emplace_back(2);
+            sim_sp += 2;
+            *need_events = std::max(*need_events, sim_sp);
+            *need_stack = std::max(*need_stack, (uint32_t)sim.size());
+            continue;
+          }
+          const uint32_t rule = q.word & 3u;
+          bool swapped = false;
+          if (rule == GMLRT_INTERSECT && lazy_operands()) {
+            const uint64_t score_a = (uint64_t)n_leaves_of(q.a) + (unbounded(q.a) ? 1000000u : 0u);
+            const uint64_t score_b = (uint64_t)n_leaves_of(q.b) + (unbounded(q.b) ? 1000000u : 0u);
+            swapped = score_b < score_a;
+          }
+          const int first = swapped ? q.b : q.a, second = swapped ? q.a : q.b;
+          // popped in reverse: first operand, (skip record), second operand, operator, close bound
+          work.push_back({stp.node, 3, bound_rec, swapped ? 1u : 0u});
+          work.push_back({second, 0, 0, 0});
+          if (rule != GMLRT_UNION && lazy_operands()) work.push_back({stp.node, 1, 0, 0});
+          work.push_back({first, 0, 0, 0});
+        } else if (stp.stage == 1) {
+          skip_open.push_back(S.bytes.size());
+          put_small(kRecSkipEmpty, 0);
+        } else {
+          const uint32_t rule = q.word & 3u;
+          // (the leaf-operand flags of the blob's word are not used by the traversal)
+          put_small(kRecOp, rule | (stp.b ? kOpSwapped : 0u));
+          {
+            const uint64_t lb = sim.back(); sim.pop_back();
+            const uint64_t la = sim.back(); sim.pop_back();
+            *need_events = std::max(*need_events, sim_sp + la + lb);  // the merge writes its output above both operands
+            sim.push_back(la + lb);
+          }
+          if (rule != GMLRT_UNION && lazy_operands()) {
+            const uint32_t to = (uint32_t)S.bytes.size();
+            std::memcpy(S.bytes.data() + skip_open.back() + offsetof(ProgSmall, arg), &to, 4);
+            skip_open.pop_back();
+          }
+          if (stp.a != (size_t)-1) patch_skip(stp.a);
         }
       }
       put_small(kRecTake, 0);

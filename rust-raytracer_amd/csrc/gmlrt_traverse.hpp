@@ -104,6 +104,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       DIAG(dg.n_bound++;)
       DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
       if (__ballot(hit)) {
+        DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(__ballot(hit));)
         pc = next;
       } else {
         DIAG(dg.n_skip++;)
@@ -133,7 +134,11 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       const bool entry = (fl & kFlActive) && (ph.bits & 1);
       const double d0 = scale * ph.tA, d1 = scale * ph.tB;
       const bool sliver = (ph.bits & 2) && (d1 - d0 < 1e-10);
-      DIAG(dg.l_lanes += (unsigned long long)__popcll(__ballot((fl & kFlActive) != 0)); dg.l_hits += (unsigned long long)__popcll(__ballot(entry));)
+      DIAG(dg.l_lanes += (unsigned long long)__popcll(__ballot((fl & kFlActive) != 0)); dg.l_hits += (unsigned long long)__popcll(__ballot(entry));
+           if (!__ballot(entry)) dg.l_nohit++;
+           { const unsigned long long be = __ballot(entry);
+             if (dg.leaf_dbg && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) { atomicAdd(&dg.leaf_dbg[leaf * 3], 1ull); if (!be) atomicAdd(&dg.leaf_dbg[leaf * 3 + 1], 1ull);
+               atomicAdd(&dg.leaf_dbg[leaf * 3 + 2], (unsigned long long)__popcll(be)); } })
       if (kf & kRecFlag) {
         // frontier leaf: no list, just a candidate for the nearest first Entry
         if (entry) {
@@ -184,11 +189,19 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
         }
       }
       DIAG(if (__ballot(general)) dg.n_merge++;)
-      if (general) lout = merge_any(rule, evD, evM, a0, la, lb);
+      if (general) lout = merge_any(R[1] & (3u | kOpSwapped), evD, evM, a0, la, lb);
       lens[(level - 2) * kBlock + tid] = (uint16_t)lout;
       sp = a0 + lout;
       level--;
       pc += (uint32_t)sizeof(ProgSmall);
+      continue;
+    }
+    if (kind == kRecSkipEmpty) {
+      // between the two operands of an intersection or a difference: the first one's list is empty for every
+      // ray of the wave, so the operator's result is empty too; that empty list stays where it is and the
+      // second operand and the operator are jumped over
+      const uint32_t l = lens[(level - 1) * kBlock + tid] & 0x7FFFu;
+      pc = __ballot(l != 0) ? pc + (uint32_t)sizeof(ProgSmall) : R[1];
       continue;
     }
     if (kind == kRecTake) {
