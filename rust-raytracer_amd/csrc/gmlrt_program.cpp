@@ -16,8 +16,8 @@
 //    candidates at the same distance still goes to the one that comes first in the blob's
 //    program; leaves are numbered in program order, so the kernel breaks ties by leaf index.
 //    That freedom is used to regroup the frontier children spatially: a binary tree of boxes
-//    over their bounds (median split of the centroids along the longest axis, nearer to the
-//    camera first), emitted in depth-first order with skip offsets.  The blob's own bounds on
+//    over their bounds (the cut of the centroid order, along any axis, that the surface-area heuristic
+//    prices lowest; nearer to the camera first), emitted in depth-first order with skip offsets.  The blob's own bounds on
 //    union nodes of the frontier are not used (a chain of unions bounds little).
 //
 // 2. Stream layout.  The program is one byte stream of 16-byte-aligned records with
@@ -58,6 +58,10 @@ double box_bias() {
 // environment override exists for tuning runs.
 bool lazy_operands() {
   static const bool v = [] { const char* e = std::getenv("GMLRT_LAZY_OPERANDS"); return !(e && *e == '0'); }();
+  return v;
+}
+bool sah_split() {
+  static const bool v = [] { const char* e = std::getenv("GMLRT_SAH"); return !(e && *e == '0'); }();  // tuning runs
   return v;
 }
 struct PNode {
@@ -393,12 +397,48 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     g.radius = std::sqrt(h2) * (1.0 + 1e-9) + 1e-12;  // the box's circumscribed sphere
     int axis = 0;
     for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-    const size_t mid = r.lo + n / 2;
-    std::nth_element(grouped.begin() + (long)r.lo, grouped.begin() + (long)mid, grouped.begin() + (long)r.hi,
-                     [&](int x, int y) {
-                       const double cx = centroid(x, axis), cy = centroid(y, axis);
-                       return cx < cy || (cx == cy && x < y);
-                     });
+    size_t mid = r.lo + n / 2;
+    auto by_centroid = [&](int ax) {
+      return [&, ax](int x, int y) {
+        const double cx = centroid(x, ax), cy = centroid(y, ax);
+        return cx < cy || (cx == cy && x < y);
+      };
+    };
+    if (sah_split()) {
+      // surface-area heuristic: along each axis, the cut of the centroid order that minimises
+      // area(left) * count(left) + area(right) * count(right)
+      auto area_of = [](const double* l, const double* h) {
+        const double e[3] = {h[0] - l[0], h[1] - l[1], h[2] - l[2]};
+        if (e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0) return 0.0;
+        return 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+      };
+      double best_cost = INFINITY;
+      int best_axis = axis;
+      size_t best_cut = n / 2;
+      std::vector<int> tmp(grouped.begin() + (long)r.lo, grouped.begin() + (long)r.hi);
+      std::vector<double> right_area(n + 1, 0.0);
+      for (int ax = 0; ax < 3; ax++) {
+        std::sort(tmp.begin(), tmp.end(), by_centroid(ax));
+        double l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = n; i-- > 0;) {
+          const gmlrt_bound& b = bounds[tree[(size_t)tmp[i]].bound];
+          for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], b.lo[k]); h[k] = std::max(h[k], b.hi[k]); }
+          right_area[i] = area_of(l, h);
+        }
+        for (int k = 0; k < 3; k++) { l[k] = INFINITY; h[k] = -INFINITY; }
+        for (size_t i = 0; i + 1 < n; i++) {
+          const gmlrt_bound& b = bounds[tree[(size_t)tmp[i]].bound];
+          for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], b.lo[k]); h[k] = std::max(h[k], b.hi[k]); }
+          const double c = area_of(l, h) * (double)(i + 1) + right_area[i + 1] * (double)(n - i - 1);
+          if (c < best_cost) { best_cost = c; best_axis = ax; best_cut = i + 1; }
+        }
+      }
+      axis = best_axis;
+      mid = r.lo + best_cut;
+      std::sort(grouped.begin() + (long)r.lo, grouped.begin() + (long)r.hi, by_centroid(axis));
+    } else {
+    std::nth_element(grouped.begin() + (long)r.lo, grouped.begin() + (long)mid, grouped.begin() + (long)r.hi, by_centroid(axis));
+    }
     // the half whose centroids lie nearer to the camera goes first
     double dl = 0.0, dr = 0.0;
     for (int k = 0; k < 3; k++) {
