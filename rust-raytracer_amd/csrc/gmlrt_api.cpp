@@ -2,6 +2,7 @@
 // multi-GPU driver (one host thread per GPU, interleaved row tiles, final gather
 // into the caller's framebuffer) and the GML program front-end handle.
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,99 @@ struct gmlrt_program {
   };
   std::vector<Call> calls;
 };
+
+// ---- the host-buffer entry points: one worker per GPU partition, with what it keeps between calls
+namespace {
+struct Worker {
+  // the scene uploaded last by this worker: a caller that renders the same scene again (same bytes) gets the
+  // handle back with everything derived from the blob, and from then on the handle learns its tile order
+  gmlrt::DeviceScene ds;
+  std::vector<uint8_t> blob;
+  int device = -1;
+  int uses = 0;
+};
+std::mutex g_render_mu;         // the host-buffer entry points run one at a time
+std::vector<Worker*> g_workers;  // by partition index; under g_render_mu
+
+void drop_scene(Worker* W) {
+  if (W->device >= 0) gmlrt::dev_scene_destroy(&W->ds);
+  W->ds = gmlrt::DeviceScene{};
+  W->blob.clear();
+  W->device = -1;
+  W->uses = 0;
+}
+
+// Scene handle of worker W for `blob` on `device` ("" on success).
+std::string worker_scene(Worker* W, const void* blob, size_t blob_bytes, int device) {
+  if (W->device == device && W->blob.size() == blob_bytes && std::memcmp(W->blob.data(), blob, blob_bytes) == 0) {
+    W->uses++;
+    W->ds.learn_order = true;  // rendered more than once: learning the hand-out order pays
+    return "";
+  }
+  drop_scene(W);
+  std::string e = gmlrt::dev_scene_create(blob, blob_bytes, device, &W->ds);
+  if (!e.empty()) {
+    gmlrt::dev_scene_destroy(&W->ds);
+    W->ds = gmlrt::DeviceScene{};
+    return e;
+  }
+  W->blob.assign((const uint8_t*)blob, (const uint8_t*)blob + blob_bytes);
+  W->device = device;
+  W->uses = 1;
+  W->ds.learn_order = false;  // as far as anyone knows this handle renders once
+  return "";
+}
+
+// Number of partitions a frame is rendered in, and the GPUs behind them.
+// GMLRT_EMULATE_PARTS=N splits the frame into N partitions however many GPUs there are (partition g runs on GPU
+// g mod n): the multi-GPU path on a box with one GPU, for tests.
+void partitions(int64_t h, int32_t tile_rows, int opened, int* n_parts, int* real_gpus) {
+  *real_gpus = opened;
+  int n = opened;
+  if (const char* e = std::getenv("GMLRT_EMULATE_PARTS")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64) n = v;
+  }
+  const int64_t n_tiles = (h + tile_rows - 1) / tile_rows;  // no point in giving a GPU nothing to do
+  if ((int64_t)n > n_tiles) n = (int)n_tiles;
+  *n_parts = n;
+}
+
+void add_stats(gmlrt_stats* total, const gmlrt_stats& st, bool sum_kernel_ms) {
+  total->rays_primary += st.rays_primary;
+  total->rays_shadow += st.rays_shadow;
+  total->rays_reflect += st.rays_reflect;
+  total->leaf_tests += st.leaf_tests;
+  total->hits += st.hits;
+  if (sum_kernel_ms) total->kernel_ms += st.kernel_ms;
+  else if (st.kernel_ms > total->kernel_ms) total->kernel_ms = st.kernel_ms;
+}
+
+template <class F>
+std::string no_throw(F&& body) {
+  try {
+    return body();
+  } catch (gmlrt::SceneTooLarge& e) {
+    return std::string("too large: ") + e.what();
+  } catch (std::bad_alloc&) {
+    return "too large: out of host memory";
+  } catch (std::exception& e) {
+    return e.what();
+  }
+}
+int status_of(const std::string& e) {
+  return fail(e.rfind("too large:", 0) == 0 ? GMLRT_ERR_SCENE_TOO_LARGE : GMLRT_ERR_HIP, e);
+}
+void release_workers() {
+  std::lock_guard<std::mutex> lk(g_render_mu);
+  for (Worker* W : g_workers) {
+    drop_scene(W);
+    delete W;
+  }
+  g_workers.clear();
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -129,6 +223,7 @@ int gmlrt_init(int n_gpus) {
 }
 
 void gmlrt_shutdown(void) {
+  release_workers();
   std::lock_guard<std::mutex> lk(g_mu);
   g_n_gpus = 0;
   gmlrt::dev_release_cached();
@@ -208,124 +303,251 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
   if (!rgb8) return fail(GMLRT_ERR_INVALID_ARG, "rgb8 is NULL");
   int rc = check_params(params);
   if (rc != GMLRT_OK) return rc;
-  int n_gpus;
+  int opened;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    n_gpus = g_n_gpus;
+    opened = g_n_gpus;
   }
-  if (n_gpus <= 0) return fail(GMLRT_ERR_NOT_INITIALISED, "call gmlrt_init first");
+  if (opened <= 0) return fail(GMLRT_ERR_NOT_INITIALISED, "call gmlrt_init first");
   if (int brc = blob_status(gmlrt::validate_blob(blob, blob_bytes))) return brc;
+  std::lock_guard<std::mutex> render_lock(g_render_mu);
   const auto t0 = std::chrono::steady_clock::now();
   const int64_t w = params->width, h = params->height;
   const int32_t tile_rows = params->tile_rows > 0 ? params->tile_rows : 8;
-  // no point in giving a GPU nothing to do
-  const int64_t n_tiles = (h + tile_rows - 1) / tile_rows;
-  // GMLRT_EMULATE_PARTS=N splits the frame into N partitions however many GPUs there are (partition g
-  // runs on GPU g mod n): the multi-GPU path of this function on a box with one GPU, for tests.
-  const int real_gpus = n_gpus;
-  if (const char* e = std::getenv("GMLRT_EMULATE_PARTS")) {
-    const int n = std::atoi(e);
-    if (n >= 1 && n <= 64) n_gpus = n;
-  }
-  if ((int64_t)n_gpus > n_tiles) n_gpus = (int)n_tiles;
+  int n_parts, real_gpus;
+  partitions(h, tile_rows, opened, &n_parts, &real_gpus);
+  while ((int)g_workers.size() < n_parts) g_workers.push_back(new Worker());
 
-  struct PerGpu {
+  struct PerPart {
     std::string err;
     gmlrt_stats st;
   };
-  std::vector<PerGpu> per((size_t)n_gpus);
+  std::vector<PerPart> per((size_t)n_parts);
+  const bool verbose = std::getenv("GMLRT_VERBOSE") != nullptr;
   auto work = [&](int g) {
     const int dev = g % real_gpus;
-    PerGpu& P = per[(size_t)g];
+    PerPart& P = per[(size_t)g];
     std::memset(&P.st, 0, sizeof(P.st));
+    Worker* W = g_workers[(size_t)g];
     gmlrt_params p = *params;
     if (p.depth < 0) p.depth = 0;
     p.tile_rows = tile_rows;
     p.part = g;
-    p.nparts = n_gpus;
-    const int64_t rows = gmlrt_part_rows(h, tile_rows, g, n_gpus);
-    gmlrt::DeviceScene ds;
-    void *d8 = nullptr, *df = nullptr;
-    const bool verbose = std::getenv("GMLRT_VERBOSE") != nullptr;
+    p.nparts = n_parts;
+    const int64_t rows = gmlrt_part_rows(h, tile_rows, g, n_parts);
     auto tick = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
       if (!verbose) return;
       const auto now = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "[gmlrt] gpu %d %s: %.2f ms\n", g, what, std::chrono::duration<double, std::milli>(now - last).count());
+      std::fprintf(stderr, "[gmlrt] part %d %s: %.2f ms\n", g, what, std::chrono::duration<double, std::milli>(now - last).count());
       last = now;
     };
-    do {
-      P.err = gmlrt::dev_scene_create(blob, blob_bytes, dev, &ds);
-      if (!P.err.empty()) break;
-      ds.learn_order = false;  // this handle renders once
-      tick("scene upload");
+    P.err = no_throw([&]() -> std::string {
+      std::string e = worker_scene(W, blob, blob_bytes, dev);
+      if (!e.empty()) return e;
+      tick(W->uses > 1 ? "scene (kept from the last call)" : "scene upload");
       const size_t n8 = (size_t)rows * (size_t)w * 3;
-      P.err = gmlrt::dev_alloc(dev, n8, &d8);
-      if (!P.err.empty()) break;
-      if (rgbf64) {
-        P.err = gmlrt::dev_alloc(dev, n8 * sizeof(double), &df);
-        if (!P.err.empty()) break;
-      }
+      void *d8 = nullptr, *df = nullptr;
+      e = gmlrt::dev_output_buffers(g, dev, n8, rgbf64 ? n8 * sizeof(double) : 0, &d8, &df);
+      if (!e.empty()) return e;
       tick("output buffers");
-      P.err = gmlrt::dev_render(&ds, p, d8, df, nullptr, &P.st);
-      if (!P.err.empty()) break;
+      e = gmlrt::dev_render(&W->ds, p, d8, df, nullptr, &P.st);
+      if (!e.empty()) return e;
       tick("render (workspace + kernel)");
-      // the final gather: each GPU's rows go straight to their place in the caller's framebuffer
-      P.err = gmlrt::dev_copy_rows_to_host(dev, rgb8, d8, (size_t)w * 3, h, tile_rows, g, n_gpus);
-      if (!P.err.empty()) break;
-      if (rgbf64)
-        P.err = gmlrt::dev_copy_rows_to_host(dev, rgbf64, df, (size_t)w * 3 * sizeof(double), h, tile_rows, g, n_gpus);
-    } while (false);
-    tick("copy to host");
-    gmlrt::dev_free(dev, d8);
-    gmlrt::dev_free(dev, df);
-    gmlrt::dev_scene_destroy(&ds);
-    tick("free");
+      // the final gather: each partition's rows go to their place in the caller's framebuffer
+      e = gmlrt::dev_copy_rows_to_host(g, dev, rgb8, d8, (size_t)w * 3, h, tile_rows, g, n_parts);
+      if (!e.empty()) return e;
+      if (rgbf64) e = gmlrt::dev_copy_rows_to_host(g, dev, rgbf64, df, (size_t)w * 3 * sizeof(double), h, tile_rows, g, n_parts);
+      tick("copy to host");
+      return e;
+    });
+    if (!P.err.empty()) drop_scene(W);
   };
-  if (n_gpus == 1) {
+  if (n_parts == 1) {
     work(0);
   } else {
     std::vector<std::thread> th;
-    for (int g = 0; g < n_gpus; g++) th.emplace_back(work, g);
+    for (int g = 0; g < n_parts; g++) th.emplace_back(work, g);
     for (auto& t : th) t.join();
   }
   gmlrt_stats total;
   std::memset(&total, 0, sizeof(total));
   for (auto& P : per) {
-    if (!P.err.empty()) return fail(GMLRT_ERR_HIP, P.err);
-    total.rays_primary += P.st.rays_primary;
-    total.rays_shadow += P.st.rays_shadow;
-    total.rays_reflect += P.st.rays_reflect;
-    total.leaf_tests += P.st.leaf_tests;
-    total.hits += P.st.hits;
-    if (P.st.kernel_ms > total.kernel_ms) total.kernel_ms = P.st.kernel_ms;
+    if (!P.err.empty()) return status_of(P.err);
+    add_stats(&total, P.st, false);
   }
   total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  total.n_gpus = (uint32_t)n_gpus;
+  total.n_gpus = (uint32_t)n_parts;
   if (stats) *stats = total;
   return GMLRT_OK;
 }
 
+// The frame is rendered in bands of whole "rounds" (one row tile per partition), top to bottom.  Each partition
+// has a producer thread that renders its share of band k + 1 while the share of band k travels to page-locked
+// host memory and the calling thread hands band k - 1 to the sink, pixel by pixel in scanline order: the caller
+// sees its first pixels after one band, and the host never holds more than two bands per partition.
 int gmlrt_render_to_sink(const void* blob, size_t blob_bytes, const gmlrt_params* params, const char* filename,
                          const gmlrt_renderer* sink, gmlrt_stats* stats) {
   if (!sink || !sink->new_image || !sink->push_pixel) return fail(GMLRT_ERR_INVALID_ARG, "sink needs new_image and push_pixel");
   int rc = check_params(params);
   if (rc != GMLRT_OK) return rc;
-  const size_t n = (size_t)params->width * (size_t)params->height * 3;
-  std::vector<uint8_t> rgb8;
-  std::vector<double> rgbf;
-  try {
-    rgb8.resize(n);
-    rgbf.resize(n);
-  } catch (std::bad_alloc&) {
-    return fail(GMLRT_ERR_SCENE_TOO_LARGE, "image does not fit in host memory");
+  int opened;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    opened = g_n_gpus;
   }
-  rc = gmlrt_render(blob, blob_bytes, params, rgb8.data(), rgbf.data(), stats);
-  if (rc != GMLRT_OK) return rc;
-  if (sink->new_image(sink->user, filename ? filename : "", params->width, params->height) != 0)
-    return fail(GMLRT_ERR_SINK, "new_image failed");
-  for (size_t i = 0; i < n; i += 3)
-    if (sink->push_pixel(sink->user, &rgbf[i]) != 0) return fail(GMLRT_ERR_SINK, "push_pixel failed");
+  if (opened <= 0) return fail(GMLRT_ERR_NOT_INITIALISED, "call gmlrt_init first");
+  if (int brc = blob_status(gmlrt::validate_blob(blob, blob_bytes))) return brc;
+  std::lock_guard<std::mutex> render_lock(g_render_mu);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int64_t w = params->width, h = params->height;
+  const int32_t tile_rows = params->tile_rows > 0 ? params->tile_rows : 8;
+  int n_parts, real_gpus;
+  partitions(h, tile_rows, opened, &n_parts, &real_gpus);
+  while ((int)g_workers.size() < n_parts) g_workers.push_back(new Worker());
+
+  // band height: about 2^20 pixels per partition and band (a few milliseconds of kernel on a heavy scene, a
+  // 25 MB host buffer), in whole rounds; GMLRT_SINK_BAND_ROWS overrides the rows per partition (tests)
+  const int64_t round_rows = (int64_t)tile_rows * n_parts;
+  int64_t part_rows_per_band = ((1ll << 20) / w / tile_rows) * tile_rows;
+  if (const char* e = std::getenv("GMLRT_SINK_BAND_ROWS")) part_rows_per_band = (std::atoll(e) / tile_rows) * tile_rows;
+  if (part_rows_per_band < tile_rows) part_rows_per_band = tile_rows;
+  const int64_t rounds_per_band = part_rows_per_band / tile_rows;
+  const int64_t n_rounds = (h + round_rows - 1) / round_rows;
+  const int64_t n_bands = (n_rounds + rounds_per_band - 1) / rounds_per_band;
+
+  struct Part {
+    gmlrt::BandPipe* pipe = nullptr;
+    std::string err;
+    gmlrt_stats st;
+    int64_t issued = 0;    // bands whose copy has been queued
+    int64_t consumed = 0;  // bands the sink is done with
+  };
+  std::vector<Part> parts((size_t)n_parts);
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false;
+  for (auto& P : parts) std::memset(&P.st, 0, sizeof(P.st));
+
+  auto produce = [&](int g) {
+    const int dev = g % real_gpus;
+    Part& P = parts[(size_t)g];
+    Worker* W = g_workers[(size_t)g];
+    gmlrt_params p = *params;
+    if (p.depth < 0) p.depth = 0;
+    p.tile_rows = tile_rows;
+    p.part = g;
+    p.nparts = n_parts;
+    const int64_t rows_all = gmlrt_part_rows(h, tile_rows, g, n_parts);
+    std::string err = no_throw([&]() -> std::string {
+      std::string e = worker_scene(W, blob, blob_bytes, dev);
+      if (!e.empty()) return e;
+      W->ds.learn_order = false;  // every band is a geometry of its own
+      e = gmlrt::band_pipe_create(dev, (size_t)part_rows_per_band * (size_t)w, &P.pipe);
+      if (!e.empty()) return e;
+      for (int64_t b = 0; b < n_bands; b++) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || P.consumed + 2 > b; });  // slot b % 2 held band b - 2
+          if (stop) return "";
+        }
+        const int64_t row0 = b * part_rows_per_band;
+        const int64_t rows = std::max<int64_t>(0, std::min(part_rows_per_band, rows_all - row0));
+        if (rows > 0) {
+          gmlrt_stats st;
+          std::memset(&st, 0, sizeof(st));
+          e = gmlrt::band_pipe_render(P.pipe, &W->ds, p, (int)(b & 1), row0, rows, &st);
+          if (!e.empty()) return e;
+          add_stats(&P.st, st, true);
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          P.issued = b + 1;
+        }
+        cv.notify_all();
+      }
+      return "";
+    });
+    if (!err.empty()) {
+      std::lock_guard<std::mutex> lk(mu);
+      P.err = err;
+      stop = true;
+    }
+    cv.notify_all();
+  };
+
+  std::vector<std::thread> th;
+  for (int g = 0; g < n_parts; g++) th.emplace_back(produce, g);
+
+  int result = GMLRT_OK;
+  std::string sink_err;
+  if (sink->new_image(sink->user, filename ? filename : "", w, h) != 0) {
+    result = GMLRT_ERR_SINK;
+    sink_err = "new_image failed";
+  }
+  for (int64_t b = 0; b < n_bands && result == GMLRT_OK; b++) {
+    // the band's share of every partition must have arrived
+    std::vector<const double*> host((size_t)n_parts, nullptr);
+    for (int g = 0; g < n_parts && result == GMLRT_OK; g++) {
+      Part& P = parts[(size_t)g];
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || P.issued > b; });
+        if (stop) { result = GMLRT_ERR_HIP; break; }
+      }
+      const int64_t row0 = b * part_rows_per_band;
+      if (gmlrt_part_rows(h, tile_rows, g, n_parts) > row0) {
+        std::string e = gmlrt::band_pipe_wait(P.pipe, (int)(b & 1), &host[(size_t)g]);
+        if (!e.empty()) { result = GMLRT_ERR_HIP; sink_err = e; }
+      }
+    }
+    if (result != GMLRT_OK) break;
+    // scanline order over the band's rounds: round r holds one row tile of every partition, in partition order
+    const int64_t y_begin = b * rounds_per_band * round_rows;
+    const int64_t y_end = std::min(h, (b + 1) * rounds_per_band * round_rows);
+    for (int64_t y = y_begin; y < y_end && result == GMLRT_OK; y++) {
+      const int64_t tile = y / tile_rows;
+      const int g = (int)(tile % n_parts);
+      const int64_t packed = (tile / n_parts) * tile_rows + y % tile_rows - b * part_rows_per_band;  // row inside the band's buffer
+      const double* row = host[(size_t)g] + (size_t)packed * (size_t)w * 3;
+      for (int64_t x = 0; x < w; x++)
+        if (sink->push_pixel(sink->user, row + x * 3) != 0) {
+          result = GMLRT_ERR_SINK;
+          sink_err = "push_pixel failed";
+          break;
+        }
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto& P : parts) P.consumed = b + 1;
+    }
+    cv.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (result != GMLRT_OK) stop = true;
+  }
+  cv.notify_all();
+  for (auto& t : th) t.join();
+  gmlrt_stats total;
+  std::memset(&total, 0, sizeof(total));
+  std::string dev_err;
+  for (int g = 0; g < n_parts; g++) {
+    Part& P = parts[(size_t)g];
+    gmlrt::band_pipe_destroy(P.pipe);
+    if (!P.err.empty()) {
+      dev_err = P.err;
+      drop_scene(g_workers[(size_t)g]);
+    }
+    // partitions render side by side: the frame's kernel time is the slowest partition's sum over its bands
+    add_stats(&total, P.st, false);
+  }
+  if (!dev_err.empty()) return status_of(dev_err);
+  if (result == GMLRT_ERR_SINK) return fail(GMLRT_ERR_SINK, sink_err);
+  if (result != GMLRT_OK) return fail(result, sink_err.empty() ? "render stopped" : sink_err);
   if (sink->done && sink->done(sink->user) != 0) return fail(GMLRT_ERR_SINK, "done failed");
+  total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  total.n_gpus = (uint32_t)n_parts;
+  if (stats) *stats = total;
   return GMLRT_OK;
 }
 

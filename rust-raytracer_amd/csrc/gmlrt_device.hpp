@@ -111,16 +111,33 @@ void dev_scene_destroy(DeviceScene* s);
 // d_rgb8 / d_rgbf are device pointers (rgbf may be null).
 // no_alloc: use the library's static scratch array instead of the handle's allocated workspace and make no
 // allocation of any kind (fewer lanes in flight when the array holds fewer; no learnt tile order).
+// band_row0 / band_rows: render only that range of the partition's packed rows (band_rows < 0: to the end);
+// the output buffers then hold the band alone.
 std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void* d_rgbf, void* stream,
-                       gmlrt_stats* stats, bool no_alloc = false);
-// Plain device buffers for the host-buffer entry point.
+                       gmlrt_stats* stats, bool no_alloc = false, int64_t band_row0 = 0, int64_t band_rows = -1);
+// Plain device buffers (tests, tools).
 std::string dev_alloc(int device, size_t bytes, void** out);
 void dev_free(int device, void* p);
 std::string dev_copy_to_host(int device, void* dst, const void* src, size_t bytes);
-// Copies the packed rows one partition rendered (device) to their places in the full image (host):
-// partition `part` of `nparts` owns the row tiles part, part + nparts, ... of `tile_rows` rows each.
-std::string dev_copy_rows_to_host(int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
+// The host-buffer entry point runs one worker per GPU partition; `worker` names its cached resources (device
+// output buffers, page-locked staging), which live until dev_release_cached.  rgbf_bytes = 0: no f64 output.
+std::string dev_output_buffers(int worker, int device, size_t rgb8_bytes, size_t rgbf_bytes, void** d8, void** df);
+// Copies the packed rows one partition rendered (device) to their places in the full image (pageable host memory),
+// through the worker's page-locked staging: partition `part` of `nparts` owns the row tiles part, part + nparts, ...
+// of `tile_rows` rows each.
+std::string dev_copy_rows_to_host(int worker, int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
                                   int32_t tile_rows, int32_t part, int32_t nparts);
+// Streaming a frame to the host band by band: two device buffers and two page-locked host buffers per GPU, so that
+// band k + 1 renders while band k is copied and band k - 1 is handed to the caller's pixel sink.
+struct BandPipe;
+std::string band_pipe_create(int device, size_t band_pixels, BandPipe** out);  // *out is set even on failure: destroy it
+void band_pipe_destroy(BandPipe* bp);
+// Renders rows [row0, row0 + rows) of the partition (packed rows) into slot 0 or 1 and queues the copy of the f64
+// pixels into that slot's host buffer.  Call only when the caller has finished with the slot's previous contents.
+std::string band_pipe_render(BandPipe* bp, DeviceScene* s, const gmlrt_params& p, int slot, int64_t row0, int64_t rows,
+                             gmlrt_stats* stats);
+// Waits until the slot's host buffer holds the band queued last; may be called from another thread than render.
+std::string band_pipe_wait(BandPipe* bp, int slot, const double** host);
 // Frees what dev_scene_destroy keeps for the next scene on the same device (scratch buffers, events).
 void dev_release_cached(void);
 

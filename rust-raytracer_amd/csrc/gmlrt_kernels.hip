@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <cmath>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -85,7 +87,8 @@ struct KArgs {
   int32_t depth;
   int32_t w, h;
   int32_t tile_rows, part, nparts;
-  int32_t rows_part;     // rows this partition renders
+  int32_t rows_part;     // rows this launch renders: the partition's packed rows band_row0 .. band_row0 + rows_part - 1
+  int32_t band_row0;
   uint32_t tiles_x;      // 8x8 pixel tiles per row band
   uint32_t n_slots;      // tiles_x * tiles_y * 64 pixel slots (padding included)
   uint8_t* rgb8;
@@ -618,10 +621,11 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         const uint32_t x = (tile % A.tiles_x) * kTileW + (in % kTileW);
         const uint32_t yl = (tile / A.tiles_x) * kTileH + (in / kTileW);
         if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
-          uint32_t y = yl;
+          const uint32_t yp = yl + (uint32_t)A.band_row0;  // packed row of the partition
+          uint32_t y = yp;
           if (A.nparts > 1) {
-            const uint32_t k = yl / (uint32_t)A.tile_rows;
-            y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yl % (uint32_t)A.tile_rows;
+            const uint32_t k = yp / (uint32_t)A.tile_rows;
+            y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yp % (uint32_t)A.tile_rows;
           }
           // raytracer.rs:138-142
           const double xf = (double)x, yf = (double)y;
@@ -750,24 +754,158 @@ std::string dev_copy_to_host(int device, void* dst, const void* src, size_t byte
   return "";
 }
 
-std::string dev_copy_rows_to_host(int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
+namespace {
+// Page-locked staging of one host worker (one per GPU partition of gmlrt_render): a ring of slots that device
+// memory is copied into by DMA while the worker copies the previous slot on into the caller's pageable buffer.
+// (hipMemcpy into pageable memory does the same inside the runtime, one step after the other: 1.9 ms for the
+// 24.9 MB of a 4K frame against 0.45 ms of DMA into page-locked memory and 0.8 ms of memcpy, which overlap here.)
+struct HostStage {
+  static constexpr int kSlots = 3;
+  int device = -1;
+  void* slot[kSlots] = {nullptr, nullptr, nullptr};
+  size_t slot_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr};
+  // device output buffers of the worker, kept between calls
+  void* d8 = nullptr;
+  void* df = nullptr;
+  size_t d8_bytes = 0, df_bytes = 0;
+};
+constexpr size_t kStageSlotBytes = 4u << 20;
+constexpr size_t kCopyThreads = 4;  // stage index = worker * kCopyThreads + thread
+std::mutex g_stage_mu;
+std::vector<HostStage*> g_stage;  // by worker index; entries are created once and live until dev_release_cached
+
+std::string stage_for(int worker, int device, HostStage** out) {
+  HostStage* st = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    if ((size_t)worker >= g_stage.size()) g_stage.resize((size_t)worker + 1, nullptr);
+    if (!g_stage[(size_t)worker]) g_stage[(size_t)worker] = new HostStage();
+    st = g_stage[(size_t)worker];
+  }
+  if (st->device != device) {
+    // (a worker index keeps its device for the life of the process in practice: partition g runs on GPU g mod n)
+    if (st->device >= 0 && hipSetDevice(st->device) == hipSuccess) {
+      for (int i = 0; i < HostStage::kSlots; i++) { if (st->slot[i]) (void)hipHostFree(st->slot[i]); if (st->ev[i]) (void)hipEventDestroy(st->ev[i]); }
+      if (st->stream) (void)hipStreamDestroy(st->stream);
+      (void)hipFree(st->d8);
+      (void)hipFree(st->df);
+      *st = HostStage();
+    }
+    HIP_TRY(hipSetDevice(device));
+    st->device = device;
+    st->slot_bytes = kStageSlotBytes;
+    HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    for (int i = 0; i < HostStage::kSlots; i++) {
+      HIP_TRY(hipHostMalloc(&st->slot[i], st->slot_bytes, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming));
+    }
+  }
+  *out = st;
+  return "";
+}
+}  // namespace
+
+std::string dev_output_buffers(int worker, int device, size_t rgb8_bytes, size_t rgbf_bytes, void** d8, void** df) {
+  HostStage* st = nullptr;
+  std::string e = stage_for(worker * (int)kCopyThreads, device, &st);
+  if (!e.empty()) return e;
+  HIP_TRY(hipSetDevice(device));
+  if (rgb8_bytes > st->d8_bytes) {
+    (void)hipFree(st->d8);
+    st->d8 = nullptr;
+    st->d8_bytes = 0;
+    HIP_TRY(hipMalloc(&st->d8, rgb8_bytes));
+    st->d8_bytes = rgb8_bytes;
+  }
+  if (rgbf_bytes > st->df_bytes) {
+    (void)hipFree(st->df);
+    st->df = nullptr;
+    st->df_bytes = 0;
+    HIP_TRY(hipMalloc(&st->df, rgbf_bytes));
+    st->df_bytes = rgbf_bytes;
+  }
+  *d8 = st->d8;
+  *df = rgbf_bytes ? st->df : nullptr;
+  return "";
+}
+
+std::string dev_copy_rows_to_host(int worker, int device, void* image, const void* d_rows, size_t row_bytes, int64_t height,
                                   int32_t tile_rows, int32_t part, int32_t nparts) {
   HIP_TRY(hipSetDevice(device));
   const int64_t rows = gmlrt_part_rows(height, tile_rows, part, nparts);
   if (rows <= 0) return "";
-  if (nparts <= 1) {
-    HIP_TRY(hipMemcpy(image, d_rows, (size_t)rows * row_bytes, hipMemcpyDeviceToHost));
+  const size_t total = (size_t)rows * row_bytes;
+  // a unit is what goes to one contiguous place of the image: the whole partition when it is the whole image,
+  // else one row tile (the partition's tiles lie nparts tiles apart in the image)
+  const size_t band = (size_t)tile_rows * row_bytes;
+  const size_t unit = nparts > 1 ? band : row_bytes;
+  HostStage* st = nullptr;
+  std::string e = stage_for(worker * (int)kCopyThreads, device, &st);
+  if (!e.empty()) return e;
+  if (unit > st->slot_bytes) {
+    // rows too long for the staging slots: the runtime's own staged copies
+    if (nparts <= 1) {
+      HIP_TRY(hipMemcpy(image, d_rows, total, hipMemcpyDeviceToHost));
+      return "";
+    }
+    const int64_t full = rows / tile_rows, rest = rows % tile_rows;
+    uint8_t* dst = (uint8_t*)image + (size_t)part * band;
+    if (full > 0)
+      HIP_TRY(hipMemcpy2D(dst, (size_t)nparts * band, d_rows, band, band, (size_t)full, hipMemcpyDeviceToHost));
+    if (rest > 0)
+      HIP_TRY(hipMemcpy(dst + (size_t)full * (size_t)nparts * band, (const uint8_t*)d_rows + (size_t)full * band,
+                        (size_t)rest * row_bytes, hipMemcpyDeviceToHost));
     return "";
   }
-  // full tiles in one strided copy, a ragged last tile after it
-  const size_t band = (size_t)tile_rows * row_bytes;
-  const int64_t full = rows / tile_rows, rest = rows % tile_rows;
-  uint8_t* dst = (uint8_t*)image + (size_t)part * band;
-  if (full > 0)
-    HIP_TRY(hipMemcpy2D(dst, (size_t)nparts * band, d_rows, band, band, (size_t)full, hipMemcpyDeviceToHost));
-  if (rest > 0)
-    HIP_TRY(hipMemcpy(dst + (size_t)full * (size_t)nparts * band, (const uint8_t*)d_rows + (size_t)full * band,
-                      (size_t)rest * row_bytes, hipMemcpyDeviceToHost));
+  // Large transfers are cut into ranges of whole units, each with a thread and a staging ring of its own: one
+  // thread copies out of page-locked memory at 10 to 30 GB/s, the DMA engines deliver more than 50.
+  const size_t n_units = (total + unit - 1) / unit;
+  size_t n_threads = total >= (32u << 20) ? kCopyThreads : 1;
+  if (n_threads > n_units) n_threads = n_units;
+  auto copy_range = [&](HostStage* hs, size_t unit_begin, size_t unit_end) -> std::string {
+    if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed in a copy thread";
+    const size_t begin = unit_begin * unit, end = std::min(total, unit_end * unit);
+    const size_t chunk = hs->slot_bytes / unit * unit;  // whole units per slot
+    const size_t n_chunks = (end - begin + chunk - 1) / chunk;
+    constexpr size_t K = HostStage::kSlots;
+    auto issue = [&](size_t c) -> hipError_t {
+      const size_t off = begin + c * chunk, len = std::min(chunk, end - off);
+      hipError_t r = hipMemcpyAsync(hs->slot[c % K], (const uint8_t*)d_rows + off, len, hipMemcpyDeviceToHost, hs->stream);
+      if (r != hipSuccess) return r;
+      return hipEventRecord(hs->ev[c % K], hs->stream);
+    };
+    for (size_t c = 0; c < K - 1 && c < n_chunks; c++) HIP_TRY(issue(c));
+    for (size_t c = 0; c < n_chunks; c++) {
+      HIP_TRY(hipEventSynchronize(hs->ev[c % K]));
+      if (c + K - 1 < n_chunks) HIP_TRY(issue(c + K - 1));  // into the slot emptied one step ago
+      const size_t off = begin + c * chunk, len = std::min(chunk, end - off);
+      const uint8_t* src = (const uint8_t*)hs->slot[c % K];
+      if (nparts <= 1) {
+        std::memcpy((uint8_t*)image + off, src, len);
+      } else {
+        for (size_t o = 0; o < len; o += band) {
+          const size_t k = (off + o) / band;  // the partition's k-th tile is tile part + k * nparts of the image
+          std::memcpy((uint8_t*)image + ((size_t)part + k * (size_t)nparts) * band, src + o, std::min(band, len - o));
+        }
+      }
+    }
+    return "";
+  };
+  if (n_threads == 1) return copy_range(st, 0, n_units);
+  std::vector<HostStage*> stages(n_threads, st);
+  for (size_t t = 1; t < n_threads; t++) {
+    e = stage_for(worker * (int)kCopyThreads + (int)t, device, &stages[t]);
+    if (!e.empty()) return e;
+  }
+  std::vector<std::string> errs(n_threads);
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < n_threads; t++)
+    th.emplace_back([&, t] { errs[t] = copy_range(stages[t], n_units * t / n_threads, n_units * (t + 1) / n_threads); });
+  errs[0] = copy_range(stages[0], 0, n_units / n_threads);
+  for (auto& x : th) x.join();
+  for (auto& x : errs) if (!x.empty()) return x;
   return "";
 }
 
@@ -790,9 +928,142 @@ void free_workspace(DeviceScene* s) {
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
 }
+
+// ---- hand-out order of the pixel tiles from per-tile costs (ticks of the first launch with a geometry)
+// order: tiles sorted by cost class (a few classes up to the dearest tile), dearest class first, image order
+// within a class: neighbouring tiles walk the same parts of the scene program, and waves that run side by
+// side should keep sharing them in cache.
+void tiles_by_cost(const std::vector<uint32_t>& ticks, uint32_t n_classes, std::vector<uint32_t>* order) {
+  const size_t n_tiles = ticks.size();
+  uint32_t top = 1;
+  for (uint32_t c : ticks) top = std::max(top, c);
+  // counting sort by class, stable
+  std::vector<uint32_t> cls(n_tiles), start(n_classes + 1, 0);
+  for (size_t i = 0; i < n_tiles; i++) {
+    cls[i] = n_classes - 1 - (uint32_t)((uint64_t)ticks[i] * n_classes / ((uint64_t)top + 1));  // 0 = dearest
+    start[cls[i] + 1]++;
+  }
+  for (uint32_t c = 0; c < n_classes; c++) start[c + 1] += start[c];
+  order->resize(n_tiles);
+  for (size_t i = 0; i < n_tiles; i++) (*order)[start[cls[i]]++] = (uint32_t)i;
+}
+// Batches over an order (null: image order), each about the same cost: a dear tile is a batch of its own,
+// cheap ones (sky, a bare floor) go up to kTileBatchMax together.  The target is a small share of what a wave
+// does in the launch, so that the last batches still even out the end.  (Batches that shrink towards the end,
+// each a fixed share of what remains per wave, measured slower: 4740 against 4830 Mrays/s on the chess frame.)
+// Two limits on the number of batches: enough of them that the last ones even out the end of the launch (two
+// dozen a wave), and few enough that the claims, which the memory system serves one at a time (about 14 ns
+// each), stay a small part of the launch: at most one claim per 56 ns of it.
+void batches_by_cost(const std::vector<uint32_t>& ticks, const std::vector<uint32_t>* order, uint64_t waves, double launch_ms,
+                     std::vector<uint32_t>* start) {
+  const size_t n_tiles = ticks.size();
+  unsigned long long total = 0;
+  for (uint32_t c : ticks) total += c;
+  static const unsigned long long per_wave = [] { const char* e = std::getenv("GMLRT_BATCHES_PER_WAVE"); return e ? (unsigned long long)std::atoi(e) : 24ull; }();  // tuning runs
+  unsigned long long n_target = waves * per_wave;
+  static const double claim_ns = [] { const char* e = std::getenv("GMLRT_CLAIM_NS"); return e ? std::atof(e) : 56.0; }();  // tuning runs
+  const unsigned long long by_claims = (unsigned long long)(launch_ms * 1e6 / claim_ns) + 1ull;
+  if (n_target > by_claims) n_target = by_claims;
+  const unsigned long long target = total / n_target + 1ull;
+  start->clear();
+  start->reserve(n_tiles + 1);
+  unsigned long long acc = 0;
+  uint32_t in_batch = 0;
+  for (size_t i = 0; i < n_tiles; i++) {
+    const unsigned long long c = ticks[order ? (*order)[i] : i];
+    if (in_batch == 0 || in_batch >= kTileBatchMax || acc + c > target) {
+      start->push_back((uint32_t)i);
+      acc = 0;
+      in_batch = 0;
+    }
+    acc += c;
+    in_batch++;
+  }
+  start->push_back((uint32_t)n_tiles);  // number of batches = size - 1
+}
 }  // namespace
 
+// ---- streaming a frame to the host band by band (the pixel sink of gmlrt_render_to_sink)
+struct BandPipe {
+  int device = -1;
+  size_t band_pixels = 0;            // capacity of a slot in pixels
+  void* d8[2] = {nullptr, nullptr};  // device: quantised band (the kernel always writes it)
+  void* df[2] = {nullptr, nullptr};  // device: f64 band
+  double* host[2] = {nullptr, nullptr};  // page-locked: f64 band
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr};
+  bool in_flight[2] = {false, false};
+};
+
+std::string band_pipe_create(int device, size_t band_pixels, BandPipe** out) {
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  BandPipe* bp = new BandPipe();
+  bp->device = device;
+  bp->band_pixels = band_pixels;
+  *out = bp;  // the caller destroys it whatever happens below
+  HIP_TRY(hipStreamCreateWithFlags(&bp->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipMalloc(&bp->d8[i], band_pixels * 3));
+    HIP_TRY(hipMalloc(&bp->df[i], band_pixels * 3 * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void**)&bp->host[i], band_pixels * 3 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&bp->copied[i], hipEventDisableTiming));
+  }
+  return "";
+}
+
+void band_pipe_destroy(BandPipe* bp) {
+  if (!bp) return;
+  if (hipSetDevice(bp->device) == hipSuccess) {
+    if (bp->copy_stream) (void)hipStreamSynchronize(bp->copy_stream);
+    for (int i = 0; i < 2; i++) {
+      (void)hipFree(bp->d8[i]);
+      (void)hipFree(bp->df[i]);
+      if (bp->host[i]) (void)hipHostFree(bp->host[i]);
+      if (bp->copied[i]) (void)hipEventDestroy(bp->copied[i]);
+    }
+    if (bp->copy_stream) (void)hipStreamDestroy(bp->copy_stream);
+  }
+  delete bp;
+}
+
+std::string band_pipe_render(BandPipe* bp, DeviceScene* s, const gmlrt_params& p, int slot, int64_t row0, int64_t rows,
+                             gmlrt_stats* stats) {
+  HIP_TRY(hipSetDevice(bp->device));
+  if ((size_t)rows * (size_t)p.width > bp->band_pixels) return "band larger than its buffers";
+  // the device buffers of this slot are free once the copy queued from them two bands ago has finished
+  if (bp->in_flight[slot]) HIP_TRY(hipEventSynchronize(bp->copied[slot]));
+  bp->in_flight[slot] = false;
+  std::string e = dev_render(s, p, bp->d8[slot], bp->df[slot], nullptr, stats, false, row0, rows);  // returns when the kernel is done
+  if (!e.empty()) return e;
+  HIP_TRY(hipMemcpyAsync(bp->host[slot], bp->df[slot], (size_t)rows * (size_t)p.width * 3 * sizeof(double), hipMemcpyDeviceToHost,
+                         bp->copy_stream));
+  HIP_TRY(hipEventRecord(bp->copied[slot], bp->copy_stream));
+  bp->in_flight[slot] = true;
+  return "";
+}
+
+std::string band_pipe_wait(BandPipe* bp, int slot, const double** host) {
+  HIP_TRY(hipEventSynchronize(bp->copied[slot]));
+  *host = bp->host[slot];
+  return "";
+}
+
 void dev_release_cached(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (HostStage* st : g_stage) {
+      if (!st) continue;
+      if (st->device >= 0 && hipSetDevice(st->device) == hipSuccess) {
+        for (int i = 0; i < HostStage::kSlots; i++) { if (st->slot[i]) (void)hipHostFree(st->slot[i]); if (st->ev[i]) (void)hipEventDestroy(st->ev[i]); }
+        if (st->stream) (void)hipStreamDestroy(st->stream);
+        (void)hipFree(st->d8);
+        (void)hipFree(st->df);
+      }
+      delete st;
+    }
+    g_stage.clear();
+  }
   std::lock_guard<std::mutex> lk(g_spare_mu);
   for (auto& w : g_spare)
     if (hipSetDevice(w.device) == hipSuccess) free_workspace(&w);
@@ -909,7 +1180,7 @@ void dev_scene_destroy(DeviceScene* s) {
 }
 
 std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void* d_rgbf, void* stream_v,
-                       gmlrt_stats* stats, bool no_alloc) {
+                       gmlrt_stats* stats, bool no_alloc, int64_t band_row0, int64_t band_rows) {
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t stream = (hipStream_t)stream_v;
   const gmlrt_blob_header& H = s->hdr;
@@ -943,8 +1214,11 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.tile_rows = p.tile_rows > 0 ? p.tile_rows : 8;
   A.part = nparts > 1 ? p.part : 0;
   A.nparts = nparts;
-  const int64_t rows = gmlrt_part_rows(p.height, A.tile_rows, A.part, nparts);
+  const int64_t rows_all = gmlrt_part_rows(p.height, A.tile_rows, A.part, nparts);
+  if (band_row0 < 0 || band_row0 > rows_all) return "band outside the partition";
+  const int64_t rows = band_rows < 0 || band_row0 + band_rows > rows_all ? rows_all - band_row0 : band_rows;
   A.rows_part = (int32_t)rows;
+  A.band_row0 = (int32_t)band_row0;
   A.tiles_x = (uint32_t)((p.width + kTileW - 1) / kTileW);
   const uint64_t tiles_y = (uint64_t)((rows + kTileH - 1) / kTileH);
   const uint64_t n_slots = (uint64_t)A.tiles_x * tiles_y * 64ull;
@@ -1060,6 +1334,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     s->d_tile_batch = s->d_tile_batch_img = nullptr;
     s->tiles_alloc = 0;
     s->order_valid = false;
+
     HIP_TRY(hipMalloc(&s->d_tile_cost, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_order, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch, (n_tiles + 1) * sizeof(uint32_t)));
@@ -1068,7 +1343,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   }
   gmlrt_params key = p;
   key.amb[0] = key.amb[1] = key.amb[2] = 0.0;  // the ambient colour moves no ray
-  key.tile_rows = A.tile_rows; key.part = A.part; key.nparts = A.nparts; key.reserved = 0;
+  key.tile_rows = A.tile_rows; key.part = A.part; key.nparts = A.nparts;
+  key.reserved = (int32_t)(band_row0 * 1315423911ll + rows);  // a band of the partition is a geometry of its own
   if (!no_alloc) {
     if (s->order_valid && std::memcmp(&key, &s->order_key, sizeof(key)) != 0) s->order_valid = false;
     if (!s->order_valid) s->order_state = 0;
@@ -1082,6 +1358,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img : nullptr;
   A.n_tiles = (uint32_t)n_tiles;
   A.stride = 1;
+  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
   static const bool no_stride = std::getenv("GMLRT_IMAGE_ORDER") != nullptr;  // tuning runs
   if (way == 0 && !no_stride && H.n_leaves > 16) {
     // No tile costs known (a handle that renders once, or the first launch of one that will learn them, or a
@@ -1094,7 +1371,6 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     while (st > 1 && gcd(st, n_tiles) != 1) st += 2;
     if (st < n_tiles) A.stride = (uint32_t)st;
   }
-  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
   A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
 #ifdef GMLRT_DIAG
   unsigned long long* d_tile_dbg = nullptr;
@@ -1204,54 +1480,17 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       }
 #endif
     }
-    const std::vector<uint32_t> ticks(cost);  // as measured, before the division into classes
-    uint32_t top = 1;
-    for (size_t i = 0; i < n_tiles; i++) top = std::max(top, cost[i]);
-    for (size_t i = 0; i < n_tiles; i++) {
-      order[i] = (uint32_t)i;
-      cost[i] = (uint32_t)((uint64_t)cost[i] * n_classes / ((uint64_t)top + 1));
-    }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    tiles_by_cost(cost, n_classes, &order);
     HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-    // Batches over that order, each about the same measured cost: a dear tile is a batch of its own,
-    // cheap ones (sky, a bare floor) go up to kTileBatchMax together.  The target is a small share of
-    // what a wave does in the launch, so that the last batches still even out the end.  (Batches that
-    // shrink towards the end, each a fixed share of what remains per wave, measured slower: 4740
-    // against 4830 Mrays/s on the chess frame.)
     {
-      unsigned long long total = 0;
-      for (uint32_t c : ticks) total += c;
-      const unsigned long long waves = (unsigned long long)grid * (kBlock / kWave);
-      // Two limits on the number of batches: enough of them that the last ones even out the end of the
-      // launch (two dozen a wave), and few enough that the claims, which the memory system serves one at
-      // a time (about 14 ns each), stay a small part of the launch: at most one claim per 56 ns of it.
-      static const unsigned long long per_wave = [] { const char* e = std::getenv("GMLRT_BATCHES_PER_WAVE"); return e ? (unsigned long long)std::atoi(e) : 24ull; }();  // tuning runs
-      unsigned long long n_target = waves * per_wave;
-      static const double claim_ns = [] { const char* e = std::getenv("GMLRT_CLAIM_NS"); return e ? std::atof(e) : 56.0; }();  // tuning runs
-      const unsigned long long by_claims = (unsigned long long)((double)ms * 1e6 / claim_ns) + 1ull;
-      if (n_target > by_claims) n_target = by_claims;
-      const unsigned long long target = total / n_target + 1ull;
-      auto build = [&](bool in_learnt_order, void* d_table, uint32_t* n_out) -> hipError_t {
-        std::vector<uint32_t> start;
-        start.reserve(n_tiles + 1);
-        unsigned long long acc = 0;
-        uint32_t in_batch = 0;
-        for (size_t i = 0; i < n_tiles; i++) {
-          const unsigned long long c = ticks[in_learnt_order ? order[i] : i];
-          if (in_batch == 0 || in_batch >= kTileBatchMax || acc + c > target) {
-            start.push_back((uint32_t)i);
-            acc = 0;
-            in_batch = 0;
-          }
-          acc += c;
-          in_batch++;
-        }
-        *n_out = (uint32_t)start.size();
-        start.push_back((uint32_t)n_tiles);
-        return hipMemcpy(d_table, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-      };
-      HIP_TRY(build(true, s->d_tile_batch, &s->n_batches));
-      HIP_TRY(build(false, s->d_tile_batch_img, &s->n_batches_img));
+      const uint64_t waves = (uint64_t)grid * (kBlock / kWave);
+      std::vector<uint32_t> start;
+      batches_by_cost(cost, &order, waves, (double)ms, &start);
+      s->n_batches = (uint32_t)start.size() - 1;
+      HIP_TRY(hipMemcpy(s->d_tile_batch, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      batches_by_cost(cost, nullptr, waves, (double)ms, &start);
+      s->n_batches_img = (uint32_t)start.size() - 1;
+      HIP_TRY(hipMemcpy(s->d_tile_batch_img, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       if (std::getenv("GMLRT_VERBOSE"))
         std::fprintf(stderr, "[gmlrt] %zu tiles in %u batches (learnt order), %u batches (image order)\n", n_tiles, s->n_batches, s->n_batches_img);
     }

@@ -1,5 +1,7 @@
 // Test-only exports: let pytest drive the host front-end and the surface compiler
 // directly (the product ABI has no reason to expose tokens or evaluator stacks).
+#include <chrono>
+#include <cmath>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -226,6 +228,44 @@ void th_transform(const double* steps, int n, double out_m[16], double out_inv[1
   }
   std::memcpy(out_m, t.m.m, sizeof(double) * 16);
   std::memcpy(out_inv, t.inv_m.m, sizeof(double) * 16);
+}
+
+// A pixel sink in C for frames too large for Python callbacks: counts the pixels, quantises each one the way
+// write_ppm_file does (raytracer.rs:21-25) and folds the bytes, in arrival order, into an FNV-1a hash; notes
+// when the first pixel arrived (nanoseconds after new_image) and the largest gap between two push_pixel calls.
+struct ThSink {
+  long long width, height, pixels, done_calls, images;
+  unsigned long long hash;
+  long long first_pixel_ns, t_new_image_ns;
+  int slow_ns;  // busy-wait per pixel, to play a slow consumer
+};
+static long long th_now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+int th_sink_new_image(void* user, const char*, long long w, long long h) {
+  ThSink* s = (ThSink*)user;
+  s->width = w; s->height = h; s->images++;
+  s->hash = 1469598103934665603ull;
+  s->t_new_image_ns = th_now_ns();
+  return 0;
+}
+int th_sink_push_pixel(void* user, const double* rgb) {
+  ThSink* s = (ThSink*)user;
+  if (s->pixels == 0) s->first_pixel_ns = th_now_ns() - s->t_new_image_ns;
+  for (int c = 0; c < 3; c++) {
+    double v = 255.0 * std::fmin(std::fmax(rgb[c], 0.0), 1.0);
+    const unsigned char b = v == v ? (unsigned char)v : 0;
+    s->hash = (s->hash ^ b) * 1099511628211ull;
+  }
+  s->pixels++;
+  if (s->slow_ns > 0) { const long long t = th_now_ns(); while (th_now_ns() - t < s->slow_ns) {} }
+  return 0;
+}
+int th_sink_done(void* user) { ((ThSink*)user)->done_calls++; return 0; }
+unsigned long long th_fnv1a(const unsigned char* p, unsigned long long n) {
+  unsigned long long h = 1469598103934665603ull;
+  for (unsigned long long i = 0; i < n; i++) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
 }
 
 }  // extern "C"

@@ -341,6 +341,61 @@ def test_renderer_sink_gets_the_image_pixel_by_pixel(gmlrt):
     assert e.value.status == -10 and len(seen) == 10
 
 
+def test_renderer_sink_streams_in_bands_and_keeps_scanline_order(gmlrt, monkeypatch):
+    # the sink is fed band by band (rows rendered while earlier ones are being pushed); whatever the band height
+    # and the number of partitions, the pixels arrive in scanline order, top row first (raytracer.rs:137-146)
+    call = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0].with_overrides(96, 77, 3)
+    _, f64, st0 = gmlrt.render(call, want_f64=True)
+    for band_rows, parts in [("8", None), ("16", None), ("8", "3"), ("24", "2"), ("1000", "8")]:
+        monkeypatch.setenv("GMLRT_SINK_BAND_ROWS", band_rows)
+        if parts:
+            monkeypatch.setenv("GMLRT_EMULATE_PARTS", parts)
+        px = []
+        st = gmlrt.render_to_sink(call, lambda f, w, h: None, lambda p: px.append(p), lambda: None)
+        monkeypatch.delenv("GMLRT_EMULATE_PARTS", raising=False)
+        got = np.array(px).reshape(77, 96, 3)
+        assert (got == f64).all(), (band_rows, parts)
+        assert st.rays == st0.rays
+    monkeypatch.delenv("GMLRT_SINK_BAND_ROWS")
+
+
+def test_renderer_sink_streams_an_8k_frame_without_holding_it(gmlrt, helpers):
+    # large.gml at its configured 7680x4320 through the sink (a C sink: 33 M Python callbacks would take minutes):
+    # the bytes, quantised as write_ppm_file does and hashed in arrival order, equal those of gmlrt_render; the host
+    # never holds the 796 MB of f64 pixels (two bands per GPU instead), and the first pixel arrives long before
+    # the last band has been rendered
+    import resource
+    call = gmlrt.Program(path=os.path.join(SCENES, "large.gml")).calls[0].with_overrides(7680, 4320, 8)
+    img, _, st0 = gmlrt.render(call)
+    L = helpers.lib
+
+    class ThSink(ctypes.Structure):
+        _fields_ = [("width", ctypes.c_longlong), ("height", ctypes.c_longlong), ("pixels", ctypes.c_longlong),
+                    ("done_calls", ctypes.c_longlong), ("images", ctypes.c_longlong), ("hash", ctypes.c_ulonglong),
+                    ("first_pixel_ns", ctypes.c_longlong), ("t_new_image_ns", ctypes.c_longlong), ("slow_ns", ctypes.c_int)]
+
+    L.th_fnv1a.restype = ctypes.c_ulonglong
+    L.th_fnv1a.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+    want_hash = L.th_fnv1a(img.ctypes.data_as(ctypes.c_void_p), img.size)
+    state = ThSink()
+    r = gmlrt.Renderer(ctypes.cast(ctypes.pointer(state), ctypes.c_void_p),
+                       ctypes.cast(L.th_sink_new_image, gmlrt.NEW_IMAGE_FN), ctypes.cast(L.th_sink_push_pixel, gmlrt.PUSH_PIXEL_FN),
+                       ctypes.cast(L.th_sink_done, gmlrt.DONE_FN))
+    st = gmlrt.Stats()
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    rc = gmlrt.lib().gmlrt_render_to_sink(call.blob, len(call.blob), ctypes.byref(call.params), b"large.ppm", ctypes.byref(r),
+                                          ctypes.byref(st))
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert rc == 0
+    assert (state.images, state.done_calls, state.pixels) == (1, 1, 7680 * 4320)
+    assert state.hash == want_hash
+    assert st.rays == st0.rays
+    print("8K sink: total %.1f ms, first pixel after %.2f ms, peak RSS grew by %.1f MB" %
+          (st.total_ms, state.first_pixel_ns / 1e6, (after - before) / 1024.0))
+    assert (after - before) / 1024.0 < 200.0          # MB; the whole frame in f64 would be 796 MB
+    assert state.first_pixel_ns / 1e6 < 0.5 * st.total_ms
+
+
 def test_in_process_multi_gpu_path_on_one_gpu(gmlrt, monkeypatch):
     # gmlrt_render with the frame split into partitions (one host thread each, strided copies straight into the
     # caller's buffers); GMLRT_EMULATE_PARTS runs every partition on the GPU that is there
