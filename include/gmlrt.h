@@ -34,7 +34,12 @@ enum gmlrt_status {
   GMLRT_ERR_IO = -7,
   GMLRT_ERR_SCENE_TOO_LARGE = -8,
   GMLRT_ERR_NOT_INITIALISED = -9,
-  GMLRT_ERR_SINK = -10           /* a gmlrt_renderer callback returned non-zero       */
+  GMLRT_ERR_SINK = -10,          /* a gmlrt_renderer callback returned non-zero       */
+  GMLRT_ERR_SURFACE = -11        /* a surface function hit a run-time error the reference aborts on
+                                    (evaluator.rs:357 `divi`/`modi` by zero, :544-555 `get` out of range) for
+                                    at least one shaded hit; the image and the statistics have been delivered
+                                    all the same, with 0 / the array's first element in place of the failed
+                                    operation                                                               */
 };
 const char* gmlrt_strerror(int status);
 /* Text of the most recent failure on the calling thread ("" if none). */
@@ -123,7 +128,7 @@ enum gmlrt_sop {
   GMLRT_SOP_ADDI,  /* evaluator.rs:315  */
   GMLRT_SOP_SUBI,  /* :480 */
   GMLRT_SOP_MULI,  /* :432 */
-  GMLRT_SOP_DIVI,  /* :357  (b == 0 yields 0 on the device; the reference panics) */
+  GMLRT_SOP_DIVI,  /* :357  (b == 0 yields 0; the reference panics: see GMLRT_SOP_TRAP) */
   GMLRT_SOP_MODI,  /* :216, 422 */
   GMLRT_SOP_EQI,   /* :371 */
   GMLRT_SOP_LESSI, /* :400 */
@@ -144,6 +149,9 @@ enum gmlrt_sop {
   GMLRT_SOP_ACOS,  /* :329 */
   GMLRT_SOP_SELECT,/* dst = a ? b : c  — an `if` (:281-302) whose two arms were both evaluated */
   GMLRT_SOP_OUT,   /* result slots dst..dst+2 = a,b,c ; slots 0..2 colour, 3 kd, 4 ks, 5 n */
+  GMLRT_SOP_TRAP,  /* a != 0: this evaluation fails in the reference (it panics: :357 division by zero, :544-555
+                      array index out of range).  a is the condition under which the failing operation is
+                      reached AND fails, so an operation on the arm of an `if` that is not taken raises nothing. */
   GMLRT_SOP__COUNT
 };
 
@@ -172,7 +180,7 @@ typedef struct gmlrt_stats {
   uint64_t leaf_tests;   /* rays * leaves                                            */
   uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
-  uint32_t reserved;
+  uint32_t surface_errors; /* non-zero: some shaded hit raised GMLRT_SOP_TRAP (the call returns GMLRT_ERR_SURFACE) */
 } gmlrt_stats;
 
 /* Operands of `render` besides the scene (evaluator.rs:749-757). */

@@ -121,7 +121,12 @@ void partitions(int64_t h, int32_t tile_rows, int opened, int* n_parts, int* rea
   *n_parts = n;
 }
 
+int surface_failure() {
+  return fail(GMLRT_ERR_SURFACE, "a surface function divided by zero or indexed an array out of range on a shaded hit "
+                                 "(the reference aborts there; the image holds 0 / the first element instead)");
+}
 void add_stats(gmlrt_stats* total, const gmlrt_stats& st, bool sum_kernel_ms) {
+  total->surface_errors |= st.surface_errors;
   total->rays_primary += st.rays_primary;
   total->rays_shadow += st.rays_shadow;
   total->rays_reflect += st.rays_reflect;
@@ -172,6 +177,7 @@ const char* gmlrt_strerror(int status) {
     case GMLRT_ERR_SCENE_TOO_LARGE: return "scene too large";
     case GMLRT_ERR_NOT_INITIALISED: return "gmlrt_init has not been called";
     case GMLRT_ERR_SINK: return "a renderer callback reported failure";
+    case GMLRT_ERR_SURFACE: return "a surface function failed at run time (division by zero or array index out of range)";
     default: return "unknown status";
   }
 }
@@ -284,7 +290,7 @@ static int render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb
     st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     st.n_gpus = 1;
     if (stats) *stats = st;
-    return GMLRT_OK;
+    return st.surface_errors ? surface_failure() : GMLRT_OK;
   });
 }
 
@@ -378,7 +384,7 @@ int gmlrt_render(const void* blob, size_t blob_bytes, const gmlrt_params* params
   total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   total.n_gpus = (uint32_t)n_parts;
   if (stats) *stats = total;
-  return GMLRT_OK;
+  return total.surface_errors ? surface_failure() : GMLRT_OK;
 }
 
 // The frame is rendered in bands of whole "rounds" (one row tile per partition), top to bottom.  Each partition
@@ -548,7 +554,7 @@ int gmlrt_render_to_sink(const void* blob, size_t blob_bytes, const gmlrt_params
   total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   total.n_gpus = (uint32_t)n_parts;
   if (stats) *stats = total;
-  return GMLRT_OK;
+  return total.surface_errors ? surface_failure() : GMLRT_OK;
 }
 
 int gmlrt_write_ppm(const char* path, const uint8_t* rgb8, int64_t w, int64_t h) {

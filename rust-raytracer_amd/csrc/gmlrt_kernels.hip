@@ -62,6 +62,7 @@ constexpr uint32_t kClaimCounters = 8, kClaimStride = 4096;
 // record, one set of ray counts per block.
 constexpr size_t kOffDiag = (size_t)kClaimCounters * kClaimStride, kOffShadeArgs = kOffDiag + 256, kOffBlockCounts = kOffDiag + 1024;
 constexpr size_t kMaxGridBlocks = 8192;
+constexpr size_t kOffSurfError = kOffBlockCounts - 8;  // inside the ShadeArgs slot, right in front of the block counts
 constexpr size_t kCountersBytes = kOffBlockCounts + kMaxGridBlocks * 4 * sizeof(unsigned long long);
 constexpr size_t kNoAllocScratchBytes = GMLRT_NOALLOC_SCRATCH_BYTES;
 constexpr size_t kStagingBytes = 1024 + kMaxGridBlocks * 4 * sizeof(unsigned long long);  // host side: ShadeArgs, then the block counts
@@ -134,9 +135,10 @@ struct ShadeArgs {
   const uint32_t* leaf_surf;   // per leaf and face (kSurfFaces slots a leaf): first record of the surface program to run
   const SurfInstr* surf_prog;  // expanded surface programs
   unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
+  uint32_t* surf_error;        // set to 1 by a lane whose own surface program raised GMLRT_SOP_TRAP
 };
 
-static_assert(sizeof(ShadeArgs) <= kOffBlockCounts - kOffShadeArgs, "ShadeArgs outgrew its slot in the counter buffer");
+static_assert(sizeof(ShadeArgs) <= kOffSurfError - kOffShadeArgs, "ShadeArgs outgrew its slot in the counter buffer");
 
 // Diagnostic build (-DGMLRT_DIAG): wave-level totals of what the traversal did and
 // where the cycles went.  Never part of the shipped library; numbers from it are
@@ -1104,7 +1106,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     uint32_t top = 2;  // face, u, v
     for (uint64_t i = 0; i < H.n_code_words; i++) {
       const uint32_t op = (uint32_t)(code[i] & 0xFF), dst = (uint32_t)((code[i] >> 8) & 0xFF);
-      if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT && dst > top) top = dst;
+      if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT && op != GMLRT_SOP_TRAP && dst > top) top = dst;
     }
     out->n_vm_regs = H.n_code_words ? (top & (GMLRT_SURF_MAX_REGS - 1)) + 1 : 0;
     if (top >= GMLRT_SURF_MAX_REGS) out->n_vm_regs = GMLRT_SURF_MAX_REGS;
@@ -1404,14 +1406,17 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.consts = d_consts;
   SA.leaf_surf = (const uint32_t*)s->d_leaf_surf;
   SA.surf_prog = (const SurfInstr*)s->d_surf;
+  SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
 #ifdef GMLRT_DIAG
   unsigned long long* d_diag_waves = nullptr;
   HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d_diag_waves, 0, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long), stream));
   SA.diag_waves = d_diag_waves;
 #endif
+  // (the whole slot: the zeros behind the record clear the surface-error word of the previous launch)
+  std::memset(s->h_staging, 0, kOffBlockCounts - kOffShadeArgs);
   std::memcpy(s->h_staging, &SA, sizeof(SA));
-  HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, sizeof(SA), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, kOffBlockCounts - kOffShadeArgs, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
   if (A.lds_ctx)
     hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
@@ -1421,8 +1426,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
+  // the surface-error word and, right behind it, the per-block ray counts
   const unsigned long long* per_block = (const unsigned long long*)((uint8_t*)s->h_staging + 1024);
-  HIP_TRY(hipMemcpyAsync((void*)per_block, d_counters + kOffBlockCounts, (size_t)grid * 4 * sizeof(unsigned long long),
+  HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 8, d_counters + kOffSurfError, 8 + (size_t)grid * 4 * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   unsigned long long counts[4] = {0, 0, 0, 0};
@@ -1598,6 +1604,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->hits = counts[3];
     stats->kernel_ms = (double)ms;
     stats->leaf_tests = (counts[0] + counts[1] + counts[2]) * (uint64_t)H.n_leaves;
+    stats->surface_errors = *(const uint32_t*)((const uint8_t*)s->h_staging + 1024 - 8) ? 1u : 0u;
   }
   return "";
 }

@@ -57,6 +57,38 @@ struct Compiler {
   std::map<std::pair<int, uint64_t>, ExprP> const_cse;
   ExprP inputs[3];
   long steps = 0;
+  // Run-time failures.  `path` is the condition under which the reference reaches the code being evaluated
+  // (the conjunction of the enclosing data-dependent `if` conditions; null: always); an operation that can
+  // fail at run time adds "path and it fails" to `traps`, and the program raises GMLRT_SOP_TRAP on their
+  // disjunction.  Operations on the arm of an `if` that is not taken therefore raise nothing, although the
+  // straight-line code computes both arms.
+  ExprP path;
+  std::vector<ExprP> traps;
+  ExprP b_and(const ExprP& a, const ExprP& b) {
+    if (!a) return b;
+    if (!b) return a;
+    if (a->is_const) return a->bits ? b : a;
+    if (b->is_const) return b->bits ? a : b;
+    return node(GMLRT_SOP_SELECT, Expr::B, a, b, kb(false));
+  }
+  ExprP b_or(const ExprP& a, const ExprP& b) {
+    if (a->is_const) return a->bits ? a : b;
+    if (b->is_const) return b->bits ? b : a;
+    return node(GMLRT_SOP_SELECT, Expr::B, a, kb(true), b);
+  }
+  ExprP b_not(const ExprP& a) {
+    if (a->is_const) return kb(!a->bits);
+    return node(GMLRT_SOP_EQI, Expr::B, a, kb(false));
+  }
+  // `fails` (a boolean expression) holds where the operation being compiled fails in the reference
+  void may_fail(const ExprP& fails, const char* what) {
+    const ExprP cond = b_and(path, fails);
+    if (cond->is_const) {
+      if (cond->bits) throw gml::GmlError(what);  // fails whenever the function is called
+      return;
+    }
+    traps.push_back(cond);
+  }
 
   Compiler() {
     for (int i = 0; i < 3; i++) {
@@ -261,8 +293,20 @@ struct Compiler {
       case Op::Addi: bin_i(GMLRT_SOP_ADDI); break;
       case Op::Subi: bin_i(GMLRT_SOP_SUBI); break;
       case Op::Muli: bin_i(GMLRT_SOP_MULI); break;
-      case Op::Divi: bin_i(GMLRT_SOP_DIVI); break;
-      case Op::Modi: bin_i(GMLRT_SOP_MODI); break;
+      case Op::Divi: case Op::Modi: {
+        // evaluator.rs:357, 422: a zero divisor panics
+        AVal b = pop(st), a = pop(st);
+        const ExprP &ea = want(a, Expr::I), &eb = want(b, Expr::I);
+        const int sop = op == Op::Divi ? GMLRT_SOP_DIVI : GMLRT_SOP_MODI;
+        if (eb->is_const && eb->iv() == 0) {
+          may_fail(kb(true), "attempt to divide by zero");
+          st.push_back(scalar(ki(0)));  // what the bytecode defines for the arm that must not be taken
+        } else {
+          if (!eb->is_const) may_fail(binop_i(GMLRT_SOP_EQI, eb, ki(0)), "attempt to divide by zero");
+          st.push_back(scalar(binop_i(sop, ea, eb)));
+        }
+        break;
+      }
       case Op::Eqi: bin_i(GMLRT_SOP_EQI); break;
       case Op::Lessi: bin_i(GMLRT_SOP_LESSI); break;
       case Op::Addf: bin_r(GMLRT_SOP_ADDF); break;
@@ -318,12 +362,18 @@ struct Compiler {
         const int64_t len = (int64_t)a.arr->size();
         if (ie->is_const) {
           const int64_t iv = ie->iv();
-          if (iv < 0 || iv >= len) throw gml::GmlError("ArrayOutOfBounds");
+          if (iv < 0 || iv >= len) {
+            may_fail(kb(true), "ArrayOutOfBounds");
+            if (len == 0) throw UnsupportedSurface("`get` on an empty array on a conditional path");
+            st.push_back((*a.arr)[(size_t)(len - 1)]);
+            break;
+          }
           st.push_back((*a.arr)[(size_t)(len - iv - 1)]);
         } else {
-          // data-dependent index: a chain of selects over the elements.  An index
-          // outside [0,len) aborts the reference; here it yields element 0.
-          if (len == 0) throw gml::GmlError("ArrayOutOfBounds");
+          // data-dependent index: a chain of selects over the elements.  An index outside
+          // [0,len) aborts the reference (evaluator.rs:544-555); here it yields element 0 and raises the trap.
+          if (len == 0) { may_fail(kb(true), "ArrayOutOfBounds"); throw UnsupportedSurface("`get` on an empty array on a conditional path"); }
+          may_fail(b_or(binop_i(GMLRT_SOP_LESSI, ie, ki(0)), binop_i(GMLRT_SOP_LESSI, ki(len - 1), ie)), "ArrayOutOfBounds");
           if (len > 256) throw UnsupportedSurface("data-dependent `get` on an array longer than 256");
           AVal r = (*a.arr)[(size_t)(len - 1)];
           for (int64_t k = 1; k < len; k++)
@@ -340,8 +390,12 @@ struct Compiler {
           call(pe->bits ? c1 : c2, st);
         } else {
           AStack s1 = st, s2 = st;
+          const ExprP outer = path;
+          path = b_and(outer, pe);
           call(c1, s1);
+          path = b_and(outer, b_not(pe));
           call(c2, s2);
+          path = outer;
           if (s1.size() != s2.size()) throw UnsupportedSurface("`if` arms leave stacks of different depth");
           st.clear();
           for (size_t k = 0; k < s1.size(); k++) st.push_back(select_val(pe, s1[k], s2[k]));
@@ -474,8 +528,10 @@ SurfaceProgram compile_surface(const gml::Value& closure) {
   out[4] = Compiler::want(ks, Expr::R);
   out[5] = Compiler::want(n, Expr::R);
 
+  ExprP trap;  // disjunction of the failure conditions collected on the way
+  for (auto& t : c.traps) trap = trap ? c.b_or(trap, t) : t;
   SurfaceProgram sp;
-  bool all_const = true;
+  bool all_const = !trap;
   for (auto& e : out) all_const = all_const && e->is_const;
   if (all_const) {
     sp.constant = true;
@@ -485,7 +541,13 @@ SurfaceProgram compile_surface(const gml::Value& closure) {
   Compiler::Emit em;
   // each OUT operand counts as a use so that its register stays live until the OUT
   for (auto& e : out) Compiler::count_uses(e);
+  if (trap) Compiler::count_uses(trap);
   for (auto& e : out) Compiler::emit_expr(em, e);
+  if (trap) {
+    Compiler::emit_expr(em, trap);
+    em.code.push_back((uint64_t)GMLRT_SOP_TRAP | ((uint64_t)Compiler::operand(em, trap) << 16));
+    Compiler::release(em, trap);
+  }
   for (int g = 0; g < 2; g++) {
     const uint32_t oa = Compiler::operand(em, out[g * 3]), ob = Compiler::operand(em, out[g * 3 + 1]),
                    oc = Compiler::operand(em, out[g * 3 + 2]);
@@ -498,14 +560,15 @@ SurfaceProgram compile_surface(const gml::Value& closure) {
   return sp;
 }
 
-void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped) {
+  if (trapped) *trapped = false;
   if (p.constant) {
     for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
     return;
   }
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
   const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
-  surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R);
+  surface_vm<true>(p.code.data(), p.consts.data(), face, u, v, out, R, trapped);
 }
 
 void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<uint8_t>& out) {
@@ -529,7 +592,8 @@ void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<ui
   }
 }
 
-void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped) {
+  if (trapped) *trapped = false;
   if (p.constant) {
     for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
     return;
@@ -538,7 +602,7 @@ void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double
   expand_surface(p.code.data(), p.consts.data(), rec);
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
   const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
-  surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, VmArrayOut{out}, R);
+  surface_stream_vm<true>((const SurfInstr*)rec.data(), face, u, v, VmArrayOut{out, trapped}, R);
 }
 
 // ---- specialisation of an expanded program for one value of `face`.
@@ -556,6 +620,7 @@ void surf_reads(uint32_t op, bool r[3]) {
     case GMLRT_SOP_END: return;
     case GMLRT_SOP_MOV: case GMLRT_SOP_REAL: case GMLRT_SOP_FLOOR: case GMLRT_SOP_SQRT: case GMLRT_SOP_FRAC:
     case GMLRT_SOP_CLAMPF: case GMLRT_SOP_SIN: case GMLRT_SOP_COS: case GMLRT_SOP_ASIN: case GMLRT_SOP_ACOS:
+    case GMLRT_SOP_TRAP:
       r[0] = true; return;
     case GMLRT_SOP_SELECT: case GMLRT_SOP_OUT: r[0] = r[1] = r[2] = true; return;
     default: r[0] = r[1] = true; return;
@@ -623,6 +688,10 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
       }
     }
     if (op == GMLRT_SOP_OUT) { fwd.push_back(I); continue; }
+    if (op == GMLRT_SOP_TRAP) {
+      if (!((I.head & imm[0]) && I.a == 0)) fwd.push_back(I);  // a failure that cannot happen on this face is dropped
+      continue;
+    }
     const uint32_t dst = (I.head >> 8) & (GMLRT_SURF_MAX_REGS - 1);
     if (op == GMLRT_SOP_SELECT) {
       const bool same = ((I.head & imm[1]) != 0) == ((I.head & imm[2]) != 0) && I.b == I.c;
@@ -663,7 +732,7 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
   for (size_t i = fwd.size(); i-- > 0;) {
     const SurfInstr& I = fwd[i];
     const uint32_t op = I.head & 0xFFu;
-    if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT) {
+    if (op != GMLRT_SOP_END && op != GMLRT_SOP_OUT && op != GMLRT_SOP_TRAP) {
       const uint32_t dst = (I.head >> 8) & (GMLRT_SURF_MAX_REGS - 1);
       if (!live[dst]) continue;
       live[dst] = false;
@@ -679,7 +748,8 @@ void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_
   }
 }
 
-void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]) {
+void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped) {
+  if (trapped) *trapped = false;
   if (p.constant) {
     for (int i = 0; i < 6; i++) out[i] = vm_as_f64(p.consts[(size_t)i]);
     return;
@@ -689,7 +759,7 @@ void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, do
   specialize_surface(rec.data(), face, spec);
   uint64_t regs[GMLRT_SURF_MAX_REGS] = {0};
   const VmRegs<uint64_t*, uint64_t*> R = {regs, 1, GMLRT_SURF_MAX_REGS, regs, 1, true, GMLRT_SURF_MAX_REGS, 0};
-  surface_stream_vm<true>((const SurfInstr*)spec.data(), face, u, v, VmArrayOut{out}, R);
+  surface_stream_vm<true>((const SurfInstr*)spec.data(), face, u, v, VmArrayOut{out, trapped}, R);
 }
 
 // ============================================================== flattening
@@ -1141,7 +1211,8 @@ std::string validate_blob(const void* blob, size_t bytes) {
       if (op >= GMLRT_SOP__COUNT) return "bad surface opcode";
       if (op == GMLRT_SOP_END) { ended = true; break; }
       const uint32_t dst = (uint32_t)((w >> 8) & 0xFF);
-      if (op == GMLRT_SOP_OUT ? (dst != 0 && dst != 3) : dst >= GMLRT_SURF_MAX_REGS) return "bad surface destination";
+      if (op == GMLRT_SOP_OUT ? (dst != 0 && dst != 3) : op == GMLRT_SOP_TRAP ? dst != 0 : dst >= GMLRT_SURF_MAX_REGS)
+        return "bad surface destination";
       for (int k = 0; k < 3; k++) {
         const uint32_t o = (uint32_t)((w >> (16 + 16 * k)) & 0xFFFF);
         if (o & 0x8000u) {

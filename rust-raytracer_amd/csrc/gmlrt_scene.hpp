@@ -41,8 +41,9 @@ SurfaceProgram compile_surface(const gml::Value& closure);
 // tree-walking evaluator).  run_surface_program goes the way the device does: it
 // expands the words into records with inline constants and interprets those;
 // run_surface_words interprets the blob's words directly.
-void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
-void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+// *trapped (optional): the evaluation raised GMLRT_SOP_TRAP, i.e. the reference would have aborted on it.
+void run_surface_program(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped = nullptr);
+void run_surface_words(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped = nullptr);
 
 // Expansion of one (code, constants) pair: appends 32-byte SurfInstr records (END
 // included) to `out`.  `code` points at the program's first word, `consts` at the
@@ -54,7 +55,7 @@ void expand_surface(const uint64_t* code, const uint64_t* consts, std::vector<ui
 // result (END included) to `out`.  What the device runs for a hit on that face.
 void specialize_surface(const uint8_t* records, int64_t face, std::vector<uint8_t>& out);
 // Host run of the specialised program (unit tests: must equal run_surface_program bit for bit).
-void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6]);
+void run_surface_specialized(const SurfaceProgram& p, int64_t face, double u, double v, double out[6], bool* trapped = nullptr);
 
 // Flattens one render call.  Throws UnsupportedSurface / gml::GmlError.
 std::vector<uint8_t> flatten_scene(const gml::RenderCall& rc);

@@ -106,9 +106,12 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
     struct HotOut {
       double* hot;
       bool mine;
+      uint32_t* err;
       __device__ void put(uint32_t first, double a, double b, double c) const {
         if (mine) { HOT(H_SC + first) = a; HOT(H_SC + first + 1) = b; HOT(H_SC + first + 2) = c; }
       }
+      // the reference would have aborted on this hit's surface evaluation (lanes that only run along do not count)
+      __device__ void trap() const { if (mine) *err = 1u; }
     };
     static_assert(H_KD == H_SC + 3 && H_KS == H_SC + 4 && H_N == H_SC + 5, "result slots 0..5 map onto H_SC..H_N");
     const ProgP progs = (ProgP)(uintptr_t)wave_uniform(SA->surf_prog);
@@ -120,7 +123,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       DIAG(vm_runs++;)
       const int src = __builtin_ctzll(todo);
       const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)mysurf, src);
-      const HotOut out = {hot, need && mysurf == cur};
+      const HotOut out = {hot, need && mysurf == cur, global_space(wave_uniform(SA->surf_error))};
       if (all_fast) surface_stream_vm<true>(progs + cur, (int64_t)face, u, v, out, R);
       else surface_stream_vm<false>(progs + cur, (int64_t)face, u, v, out, R);
       if (mysurf == cur) need = false;

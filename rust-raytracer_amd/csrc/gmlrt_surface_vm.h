@@ -91,7 +91,8 @@ GMLRT_HD uint64_t vm_operand(ConstP consts, const RegsT& R, uint32_t x) {
 
 // Runs `code` until GMLRT_SOP_END.  consts points at this surface's first constant.
 template <bool kAllFast, class CodeP, class ConstP, class RegsT>
-GMLRT_HD void surface_vm(CodeP code, ConstP consts, int64_t face, double u, double v, double out[6], const RegsT R) {
+GMLRT_HD void surface_vm(CodeP code, ConstP consts, int64_t face, double u, double v, double out[6], const RegsT R,
+                         bool* trapped = nullptr) {
   vm_set<kAllFast>(R, 0, (uint64_t)face);
   vm_set<kAllFast>(R, 1, vm_from_f64(u));
   vm_set<kAllFast>(R, 2, vm_from_f64(v));
@@ -138,6 +139,9 @@ GMLRT_HD void surface_vm(CodeP code, ConstP consts, int64_t face, double u, doub
         else if (dst == 3) { out[3] = fa; out[4] = fb; out[5] = fc; }
         continue;
       }
+      case GMLRT_SOP_TRAP:
+        if (a && trapped) *trapped = true;
+        continue;
       default: break;
     }
     vm_set<kAllFast>(R, dst & (GMLRT_SURF_MAX_REGS - 1), res);
@@ -176,7 +180,9 @@ GMLRT_HD SurfInstr vm_fetch(ProgP prog, uint32_t pc) {
 // stores them where the shading code reads them, so that no result is carried through the interpreter loop.
 struct VmArrayOut {
   double* out;
+  bool* trapped = nullptr;
   GMLRT_HD void put(uint32_t first, double a, double b, double c) const { out[first] = a; out[first + 1] = b; out[first + 2] = c; }
+  GMLRT_HD void trap() const { if (trapped) *trapped = true; }
 };
 
 template <bool kAllFast, class ProgP, class RegsT, class OutT>
@@ -232,6 +238,10 @@ GMLRT_HD void surface_stream_vm(ProgP prog, int64_t face, double u, double v, co
         I = next;
         continue;
       }
+      case GMLRT_SOP_TRAP:
+        if (a) out.trap();
+        I = next;
+        continue;
       default: break;
     }
     vm_set<kAllFast>(R, dst & (GMLRT_SURF_MAX_REGS - 1), res);

@@ -33,12 +33,12 @@ class Params(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("rays_primary", ctypes.c_uint64), ("rays_shadow", ctypes.c_uint64), ("rays_reflect", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("leaf_tests", ctypes.c_uint64),
-                ("hits", ctypes.c_uint64), ("n_gpus", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("hits", ctypes.c_uint64), ("n_gpus", ctypes.c_uint32), ("surface_errors", ctypes.c_uint32)]
 
     def as_dict(self):
         return {"primary": self.rays_primary, "shadow": self.rays_shadow, "reflect": self.rays_reflect,
                 "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "leaf_tests": self.leaf_tests, "hits": self.hits,
-                "n_gpus": self.n_gpus}
+                "n_gpus": self.n_gpus, "surface_errors": self.surface_errors}
 
     @property
     def rays(self):
@@ -56,11 +56,15 @@ class Renderer(ctypes.Structure):
                 ("done", DONE_FN)]
 
 
+ERR_SURFACE = -11  # a surface function failed at run time; the outputs were delivered all the same
+
+
 class GmlrtError(RuntimeError):
-    def __init__(self, status, where):
+    def __init__(self, status, where, result=None):
         L = lib()
         super().__init__("%s: %s: %s" % (where, L.gmlrt_strerror(status).decode(), L.gmlrt_last_error().decode()))
         self.status = status
+        self.result = result  # ERR_SURFACE: what the call delivered
 
 
 _LIB = None
@@ -190,9 +194,11 @@ def render(call, want_f64=False):
     rgb8 = np.zeros((p.height, p.width, 3), dtype=np.uint8)
     f64 = np.zeros((p.height, p.width, 3), dtype=np.float64) if want_f64 else None
     st = Stats()
-    _check(lib().gmlrt_render(call.blob, len(call.blob), ctypes.byref(p), rgb8.ctypes.data_as(ctypes.c_void_p),
-                              f64.ctypes.data_as(ctypes.c_void_p) if want_f64 else None, ctypes.byref(st)),
-           "gmlrt_render")
+    rc = lib().gmlrt_render(call.blob, len(call.blob), ctypes.byref(p), rgb8.ctypes.data_as(ctypes.c_void_p),
+                            f64.ctypes.data_as(ctypes.c_void_p) if want_f64 else None, ctypes.byref(st))
+    if rc == ERR_SURFACE:
+        raise GmlrtError(rc, "gmlrt_render", (rgb8, f64, st))
+    _check(rc, "gmlrt_render")
     return rgb8, f64, st
 
 

@@ -219,6 +219,43 @@ int th_surface_eval_text(const char* text, const char* var, long long face, doub
   }
 }
 
+// Does the compiled closure raise the run-time failure the reference aborts on (evaluator.rs:357, 544-555)?
+// Returns 1 / 0 as the three interpreters report it (they must agree), and in *ref_failed whether the tree-walking
+// evaluator threw on the same call; -1 on any other error.
+int th_surface_traps(const char* text, const char* var, long long face, double u, double v, int* ref_failed,
+                     double got[6], char* err, int errlen) {
+  try {
+    gml::Evaluator ev(nullptr);
+    gml::Env env; gml::Stack st;
+    ev.run(text, env, st);
+    const gml::ValuePtr* c = env.get(var);
+    if (!c) { put("unbound", err, errlen); return -1; }
+    *ref_failed = 0;
+    try {
+      gml::Vec3 col; double kd, ks, n;
+      ev.call_surface(**c, face, u, v, &col, &kd, &ks, &n);
+    } catch (std::exception& e) {
+      *ref_failed = 1;
+      put(e.what(), err, errlen);
+    }
+    gmlrt::SurfaceProgram sp = gmlrt::compile_surface(**c);
+    bool t1 = false, t2 = false, t3 = false;
+    double g2[6], g3[6];
+    gmlrt::run_surface_program(sp, face, u, v, got, &t1);
+    gmlrt::run_surface_words(sp, face, u, v, g2, &t2);
+    gmlrt::run_surface_specialized(sp, face, u, v, g3, &t3);
+    if (t1 != t2 || t1 != t3) { put("the interpreters disagree about the trap", err, errlen); return -1; }
+    if (std::memcmp(got, g2, sizeof(g2)) != 0 || std::memcmp(got, g3, sizeof(g3)) != 0) { put("the interpreters disagree", err, errlen); return -1; }
+    return t1 ? 1 : 0;
+  } catch (gmlrt::UnsupportedSurface& e) {
+    put(std::string("UNSUPPORTED ") + e.what(), err, errlen);
+    return -2;
+  } catch (std::exception& e) {
+    put(e.what(), err, errlen);
+    return -1;
+  }
+}
+
 // Transform builder check: applies a sequence of steps (kind, p0,p1,p2)* and returns m and inv_m (row-major 4x4 each).
 void th_transform(const double* steps, int n, double out_m[16], double out_inv[16]) {
   gml::Transform t;

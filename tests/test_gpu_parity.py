@@ -396,6 +396,37 @@ def test_renderer_sink_streams_an_8k_frame_without_holding_it(gmlrt, helpers):
     assert state.first_pixel_ns / 1e6 < 0.5 * st.total_ms
 
 
+def test_surface_run_time_errors_are_reported(gmlrt, oracle):
+    # evaluator.rs:357 / 544-555: `divi` by zero and `get` out of range abort the reference inside a surface call.
+    # The device cannot abort; it delivers the image (0 / first element in place of the failed operation) and the
+    # call returns GMLRT_ERR_SURFACE -- but only if a shaded hit really took the failing path.
+    scene = ('%s sphere /s 1.0 1.0 1.0 point [ 1.0 -1.0 1.0 point 1.0 1.0 1.0 point light ] s 180.0 rotatey 0.0 0.0 2.0 translate '
+             '2 90.0 96 64 "e.ppm" render')
+    # u = atan2(x, z) on a sphere (primitives.rs:403-412): floor(u) is 0 on a stripe of it, turned towards the camera here
+    bad = "{ /v /u /face 6 u floor divi real 0.1 mulf /c c 0.5 0.5 point 1.0 0.2 4.0 }"
+    guarded = "{ /v /u /face u floor /k k 0 eqi { 0 } { 6 k divi } if real 0.1 mulf /c c 0.5 0.5 point 1.0 0.2 4.0 }"
+    with pytest.raises(gmlrt.GmlrtError) as e:
+        gmlrt.render(gmlrt.Program(text=scene % bad).calls[0], want_f64=True)
+    assert e.value.status == -11
+    img_bad, f64_bad, st_bad = e.value.result
+    assert st_bad.surface_errors == 1 and st_bad.rays_primary == 96 * 64
+    # the guarded function computes the same colours and never fails: same bytes, status OK, and the oracle agrees
+    img, f64, st = gmlrt.render(gmlrt.Program(text=scene % guarded).calls[0], want_f64=True)
+    assert st.surface_errors == 0
+    assert (img == img_bad).all() and (f64.view(np.uint64) == f64_bad.view(np.uint64)).all()
+    ref, ref64, cnt = oracle.OracleProgram(text=scene % guarded).render(0, want_f64=True, threads=4)
+    assert (img == ref).all() and st.rays == sum(cnt.values())
+    # `get`: the index floor(u) + 4 runs over 0..7 on a sphere (u = atan2 in radians); an array of four fails where
+    # u >= 0, an array of eight never does
+    surf = "{ /v /u /face a u floor 4 addi get /c c c c point 1.0 0.0 1.0 }"
+    view = ' sphere /s 1.0 1.0 1.0 point [ ] s 0.0 0.0 2.0 translate 0 90.0 96 64 "e.ppm" render'
+    with pytest.raises(gmlrt.GmlrtError) as e2:
+        gmlrt.render(gmlrt.Program(text="[ 0.2 0.4 0.6 0.8 ] /a " + surf + view).calls[0])
+    assert e2.value.status == -11
+    _, _, st_ok = gmlrt.render(gmlrt.Program(text="[ 0.2 0.4 0.6 0.8 0.1 0.3 0.5 0.7 ] /a " + surf + view).calls[0])
+    assert st_ok.surface_errors == 0
+
+
 def test_in_process_multi_gpu_path_on_one_gpu(gmlrt, monkeypatch):
     # gmlrt_render with the frame split into partitions (one host thread each, strided copies straight into the
     # caller's buffers); GMLRT_EMULATE_PARTS runs every partition on the GPU that is there

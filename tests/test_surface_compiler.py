@@ -80,3 +80,49 @@ def test_unsupported_surfaces_are_reported(helpers):
     rc, *_, err = _eval(helpers, "{ /self /x x 0.0 lessf { x } { x 1.0 subf self self apply } if } /f "
                                  "{ /v /u /face u f f apply v v point 1.0 0.0 1.0 } /s", "s", 0, 5.0, 0.5)
     assert rc == -2 and err.startswith("UNSUPPORTED")
+
+
+def _traps(helpers, text, var, face, u, v):
+    got = (ctypes.c_double * 6)()
+    ref_failed = ctypes.c_int()
+    err = ctypes.create_string_buffer(512)
+    helpers.lib.th_surface_traps.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_double,
+                                             ctypes.c_double, ctypes.POINTER(ctypes.c_int),
+                                             ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+    rc = helpers.lib.th_surface_traps(text.encode(), var.encode(), face, u, v, ctypes.byref(ref_failed), got, err, 512)
+    return rc, bool(ref_failed.value), list(got), err.value.decode()
+
+
+def test_run_time_failures_raise_the_trap_exactly_where_the_reference_aborts(helpers):
+    # evaluator.rs:357 (divi by zero), :422 (modi), :544-555 (get out of range) abort the reference at run time.
+    # The straight-line bytecode computes both arms of an `if`, so the trap carries the path condition: it is
+    # raised where the tree-walking evaluator throws and nowhere else.
+    cases = {
+        # k = floor(u) is zero for u in [0, 1)
+        "div": "{ /v /u /face 6 u floor divi real 0.1 mulf /c c c c point 1.0 0.0 1.0 } /s",
+        "mod": "{ /v /u /face 7 u floor modi real 0.1 mulf /c c c c point 1.0 0.0 1.0 } /s",
+        # the same division guarded by an `if`: never fails, whatever u
+        "guarded": "{ /v /u /face u floor /k k 0 eqi { 0 } { 6 k divi } if real 0.1 mulf /c c c c point 1.0 0.0 1.0 } /s",
+        # the division sits on the arm taken only for k = 0: fails exactly there
+        "wrong-guard": "{ /v /u /face u floor /k k 0 eqi { 6 k divi } { 1 } if real 0.1 mulf /c c c c point 1.0 0.0 1.0 } /s",
+        # array of three indexed by floor(u): fails outside 0..2
+        "get": "[ 0.1 0.5 0.9 ] /a { /v /u /face a u floor get /c c c c point 1.0 0.0 1.0 } /s",
+        # nested: fails only for face 1 and k = 0
+        "nested": "{ /v /u /face u floor /k face 1 eqi { k 0 lessi { 1 } { 5 k modi } if } { 2 } if real /c c c c point 1.0 0.0 1.0 } /s",
+    }
+    for name, text in cases.items():
+        for face in (0, 1):
+            for u in (-2.5, -0.5, 0.0, 0.5, 1.0, 2.5, 3.5):
+                rc, ref_failed, got, err = _traps(helpers, text, "s", face, u, 0.25)
+                assert rc in (0, 1), (name, err)
+                assert bool(rc) == ref_failed, (name, face, u, err)
+    # spot checks of the expectation itself
+    assert _traps(helpers, cases["div"], "s", 0, 0.5, 0.0)[0] == 1 and _traps(helpers, cases["div"], "s", 0, 1.5, 0.0)[0] == 0
+    assert all(_traps(helpers, cases["guarded"], "s", 0, u, 0.0)[0] == 0 for u in (0.0, 0.5, 3.0))
+    assert _traps(helpers, cases["get"], "s", 0, 3.0, 0.0)[0] == 1 and _traps(helpers, cases["get"], "s", 0, 2.9, 0.0)[0] == 0
+    assert _traps(helpers, cases["nested"], "s", 1, 0.5, 0.0)[0] == 1 and _traps(helpers, cases["nested"], "s", 0, 0.5, 0.0)[0] == 0
+
+
+def test_a_failure_on_every_call_is_still_a_compile_time_error(helpers):
+    rc, _, _, err = _traps(helpers, "{ /v /u /face 1 0 divi real /c c c c point 1.0 0.0 1.0 } /s", "s", 0, 0.5, 0.5)
+    assert rc == -1 and "divide by zero" in err
