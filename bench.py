@@ -19,6 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before gmlrt: one HIP runtime per process)
 import torch.distributed as dist  # noqa: E402
 
@@ -35,19 +36,39 @@ F_PRIM = {0: 61, 1: 60, 2: 70, 3: 77, 4: 47}
 F_SHADE = 150
 PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X vector FP64 (the path computes in f64)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32, the figure the project metric names
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")
 
 
 def measured_counters(workload):
-    """Memory-side bytes per launch and VALU busy fraction of the headline workload, as collected with
-    rocprofv3 --pmc (tools/profile_round.sh) and committed under profiles/; None for any other workload."""
+    """Counters of the headline workload collected with rocprofv3 --pmc (tools/profile_round.sh) and committed under
+    profiles/: executed f64 flops, memory-side bytes and VALU busy fraction, all per launch.  What a launch executes
+    does not depend on when it runs, so the counts are replayed here and divided by the kernel time measured live;
+    they are replayed only while the kernel sources are the ones they were taken from (tools/source_hash.py), and only
+    for the headline workload.  Otherwise None."""
     if workload != "chess.gml 3840x2160 depth 5":
-        return None, None
+        return None
     try:
-        d = json.load(open(PMC_SUMMARY))["derived"]
-        return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], d["valu_busy_fraction"]
-    except (OSError, KeyError, ValueError):
-        return None, None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import source_hash
+        doc = json.load(open(PMC_SUMMARY))
+        if doc.get("kernel_source_hash") != source_hash():
+            return None
+        return doc["derived"]
+    except (OSError, KeyError, ValueError, ImportError):
+        return None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a child process
+    (before this process has touched the GPU) and pass its exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def scene_flops_per_ray(blob):
@@ -92,18 +113,47 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the first-frame / host-buffer measurements")
+    ap.add_argument("--backend", default=None, help="process group backend (default nccl; gloo for CPU rehearsals of the launch path)")
+    ap.add_argument("--gather", choices=["host", "rccl"], default="host")
+    ap.add_argument("--verify", action="store_true", help="rank 0 compares the gathered frame with one it renders alone")
+    ap.add_argument("--dry-run", action="store_true", help="set up the ranks, print what would run, render nothing")
     ap.add_argument("--scene", default=SCENE)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--depth", type=int, default=DEPTH)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be one (never print a one-GPU line for an N-GPU request)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (ranks beyond the visible GPUs share them: rehearsals of the N-rank path on a box with fewer GPUs, gloo only)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    backend = args.backend or "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    if args.dry_run:
+        # the launch path alone (tests run it on CPU with gloo): every rank reports, rank 0 prints the roll call
+        me = torch.tensor([rank], dtype=torch.int64)
+        ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(ranks, me)
+        else:
+            ranks = [me]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [int(r) for r in ranks],
+                              "rows_per_rank": [gmlrt.part_rows(args.height, TILE_ROWS, r, world) for r in range(world)]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -119,24 +169,38 @@ def main():
     p.tile_rows, p.part, p.nparts = TILE_ROWS, rank, world
     # padded so every rank gathers equal shapes
     out = torch.zeros((rowtiles.padded_rows(h, TILE_ROWS, world), w, 3), dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # The final framebuffer gather, the only exchange of a step.  "host" (default): the frame is one host buffer all
+    # ranks have mapped and every rank copies its rows from its GPU straight to their places, all at once; "rccl":
+    # dist.gather of the packed rows into rank 0's HBM.
+    gathered = shared = None
+    if world > 1 and args.gather == "rccl":
+        gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+    elif world > 1:
+        shared = rowtiles.SharedFramebuffer(h, w, 3, tile_rows=TILE_ROWS)
     stream = torch.cuda.current_stream().cuda_stream
+    gather_s = [0.0]
 
     def step():
-        st = scene.render_into(p, out.data_ptr(), None, stream)
+        st = scene.render_into(p, out.data_ptr(), None, stream)  # returns when the kernel is done
         if world > 1:
-            rowtiles.gather_to_rank0(out, gathered)  # the final framebuffer gather: the only collective
+            t = time.perf_counter()
+            if shared is not None:
+                shared.put_rows_from_device(local_rank, out.data_ptr())
+            else:
+                rowtiles.gather_to_rank0(out, gathered)
+                torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - t
         return st
 
     # Scene preparation, like the upload above: the library times the pixel tiles in the first launch with a
     # given geometry and tries two other ways of handing them out in the second and third (gmlrt_kernels.hip).
-    for _ in range(3):
-        scene.render_into(p, out.data_ptr(), None, stream)
+    learn_ms = [scene.render_into(p, out.data_ptr(), None, stream).kernel_ms for _ in range(3)]
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     rays = kernel_ms = hits = 0
     for _ in range(args.steps):
@@ -150,27 +214,48 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # whole-job figures: max time over ranks, rays summed over ranks
-    agg = torch.tensor([elapsed, kernel_ms / max(args.steps, 1)], dtype=torch.float64, device=dev)
-    tot = torch.tensor([rays, hits], dtype=torch.float64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    agg = torch.tensor([elapsed, kernel_ms / max(args.steps, 1), gather_s[0] / max(args.steps, 1)], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([rays, hits], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(agg, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed_max, kernel_ms_max = agg.tolist()
+    elapsed_max, kernel_ms_max, gather_s_max = agg.tolist()
     rays_all, hits_all = tot.tolist()
 
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
         rays_per_step = rays_all / args.steps
         value = rays_per_step / (ms_per_step * 1e-3) / 1e6
-        # roofline of the render kernel on rank 0's GPU: its own rays / its own HIP-event duration
+        # roofline of the render kernel on rank 0's GPU: its own work / its own HIP-event duration
         my_rays = rays / args.steps
         my_hits = hits / args.steps
         my_kernel_ms = kernel_ms / args.steps
-        flops = my_rays * flops_per_ray + my_hits * F_SHADE
-        achieved = flops / (my_kernel_ms * 1e-3) / 1e12
         workload = "%s %dx%d depth %d" % (os.path.basename(args.scene), w, h, call.params.depth)
         headline = workload == "chess.gml 3840x2160 depth 5"
-        traffic, valu_busy = measured_counters(workload) if world == 1 else (None, None)
+        pmc = measured_counters(workload) if world == 1 else None
+        # what the reference's brute force would execute for these rays (every primitive for every ray): a rate of
+        # useful results, most of which the kernel obtains by culling; never a fraction of a hardware peak
+        equiv = (my_rays * flops_per_ray + my_hits * F_SHADE) / (my_kernel_ms * 1e-3) / 1e12
+        roofline = {"bound": "valu", "achieved": None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "kernel": "render_kernel", "kernel_ms": round(my_kernel_ms, 4),
+                    "kernel_Mrays_per_s": round(my_rays / (my_kernel_ms * 1e-3) / 1e6, 3),
+                    "traffic": None, "algorithmic_equiv_tflops": round(equiv, 3),
+                    "algorithmic_equiv_note": "rays x the flops the reference's brute force spends per ray (%d on this scene) + "
+                                              "150 per shaded hit, over kernel time: useful results, not executed work" % flops_per_ray}
+        if pmc:
+            achieved = pmc["f64_flops_per_launch"] / (my_kernel_ms * 1e-3) / 1e12
+            roofline.update({
+                "achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP64_VALU_TFLOPS, 4),
+                "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                "achieved_note": "executed f64 flops per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,TRANS}_F64 + 2 x FMA_F64, x mean "
+                                 "active lanes; %s, taken from these kernel sources) / kernel time measured here" % os.path.basename(PMC_SUMMARY),
+                "f64_flops_per_launch": pmc["f64_flops_per_launch"],
+                "traffic": pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"],
+                "valu_busy_measured": pmc["valu_busy_fraction"]})
+        else:
+            roofline["achieved_note"] = ("no executed-flop count for this workload and these kernel sources under profiles/ "
+                                         "(tools/profile_round.sh collects one)")
         line = {
             "metric": "Mrays/s (primary+shadow+reflect), " + ("chess.gml 4K depth 5" if headline else workload),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -178,23 +263,68 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "leaves": n_leaves, "flops_per_ray": flops_per_ray,
-                       "rays_per_frame": int(rays_per_step), "parallelism": "row-tiles x%d (tile %d rows)" % (world, TILE_ROWS)},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP64_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_VALU_TFLOPS, 5),
-                         "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 5),
-                         "kernel": "render_kernel", "kernel_ms": round(my_kernel_ms, 4),
-                         "kernel_Mrays_per_s": round(my_rays / (my_kernel_ms * 1e-3) / 1e6, 3),
-                         "traffic": traffic, "valu_busy_measured": valu_busy,
-                         "note": "achieved counts the reference's brute-force work per ray (every primitive tested, "
-                                 "15328 flops on this scene), most of which the bounds cull: it is a rate of useful "
-                                 "results, not of executed flops; valu_busy_measured is the physical VALU issue utilisation"},
+                       "rays_per_frame": int(rays_per_step), "parallelism": "row-tiles x%d (tile %d rows)" % (world, TILE_ROWS),
+                       "gather": ("host framebuffer shared by the ranks, every rank copies its own rows" if shared is not None else
+                                  "dist.gather to rank 0" if world > 1 else "none")},
+            "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
+            "gather_ms_per_step": round(gather_s_max * 1e3, 4) if world > 1 else None,
+            "learning_launch_kernel_ms": [round(x, 4) for x in learn_ms],
+            "roofline": roofline,
         }
+        if args.verify:
+            whole = gmlrt.Params()
+            ctypes.memmove(ctypes.byref(whole), ctypes.byref(call.params), ctypes.sizeof(whole))
+            whole.tile_rows, whole.part, whole.nparts = TILE_ROWS, 0, 1
+            ref = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+            scene.render_into(whole, ref.data_ptr(), None, stream)
+            if shared is not None:
+                got = torch.from_numpy(np.array(shared.frame))
+            elif world > 1:
+                got = rowtiles.assemble(gathered, h, TILE_ROWS).cpu()
+            else:
+                got = out[:h].cpu()
+            line["verified"] = bool((got == ref.cpu()).all())
+        if world == 1 and not args.no_host_path:
+            line["one_shot"] = one_shot(call)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     scene.close()
+    if shared is not None:
+        shared.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def one_shot(call):
+    """The same frame the way the reference's `render` is called: once, with host buffers (gmlrt_render: validate and
+    upload the scene, render with no tile order learnt, copy the rows into pageable memory).  A small other scene is
+    rendered in between so that the library has nothing of this one left.  Medians of five."""
+    other = gmlrt.Program(path=os.path.join(ROOT, "scenes", "spheres.gml")).calls[0]
+    gmlrt.render(call)
+    wall, kern, wall64 = [], [], []
+    for want in (False, True):
+        for _ in range(5):
+            gmlrt.render(other)
+            t = time.perf_counter()
+            _, _, st = gmlrt.render(call, want_f64=want)
+            (wall64 if want else wall).append((time.perf_counter() - t) * 1e3)
+            if not want:
+                kern.append(st.kernel_ms)
+    med = lambda v: round(sorted(v)[len(v) // 2], 3)  # noqa: E731
+    return {"first_frame_kernel_ms": med(kern), "e2e_ms_host_buffers": med(wall), "e2e_ms_host_buffers_with_f64_pixels": med(wall64),
+            "e2e_Mrays_per_s": round(call_rays(call) / med(wall) / 1e3, 1),
+            "note": "gmlrt_render into pageable numpy arrays allocated per call; never part of `value`"}
+
+
+_RAYS = {}
+
+
+def call_rays(call):
+    key = id(call)
+    if key not in _RAYS:
+        _RAYS[key] = gmlrt.render(call)[2].rays
+    return _RAYS[key]
 
 
 if __name__ == "__main__":

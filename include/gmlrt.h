@@ -177,7 +177,7 @@ typedef struct gmlrt_stats {
   uint64_t rays_reflect; /* one per hit with ks > 0 && depth > 0 (raytracer.rs:100)  */
   double kernel_ms;      /* device time of the render kernel (HIP events; max over GPUs) */
   double total_ms;       /* host wall time of the call                               */
-  uint64_t leaf_tests;   /* rays * leaves                                            */
+  uint64_t reserved64;   /* 0                                                        */
   uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
   uint32_t surface_errors; /* non-zero: some shaded hit raised GMLRT_SOP_TRAP (the call returns GMLRT_ERR_SURFACE) */
@@ -230,6 +230,14 @@ void gmlrt_scene_destroy(gmlrt_scene* s);
  * long as the later ones).  The images are the same whatever the order. */
 int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
                         void* hip_stream, gmlrt_stats* stats);
+
+/* The final framebuffer gather of the one-process-per-GPU form: copies the packed rows a partition rendered
+ * (d_rows, device memory, as gmlrt_render_device left them) to their places in a host framebuffer of `height` rows of
+ * `row_bytes` each (w*3 for rgb8, w*24 for f64).  `image` is ordinary host memory; it may be a shared mapping that
+ * every rank of a node has open, so that all ranks deliver their rows at once, each over its own GPU's link, and no
+ * rank has to receive the others' rows first.  Replaces nothing in the reference (one process, one image). */
+int gmlrt_copy_rows_to_host(int device, const void* d_rows, void* image, size_t row_bytes, int64_t height,
+                            int32_t tile_rows, int32_t part, int32_t nparts);
 
 /* gmlrt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments,

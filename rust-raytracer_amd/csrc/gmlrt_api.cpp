@@ -130,7 +130,6 @@ void add_stats(gmlrt_stats* total, const gmlrt_stats& st, bool sum_kernel_ms) {
   total->rays_primary += st.rays_primary;
   total->rays_shadow += st.rays_shadow;
   total->rays_reflect += st.rays_reflect;
-  total->leaf_tests += st.leaf_tests;
   total->hits += st.hits;
   if (sum_kernel_ms) total->kernel_ms += st.kernel_ms;
   else if (st.kernel_ms > total->kernel_ms) total->kernel_ms = st.kernel_ms;
@@ -291,6 +290,19 @@ static int render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb
     st.n_gpus = 1;
     if (stats) *stats = st;
     return st.surface_errors ? surface_failure() : GMLRT_OK;
+  });
+}
+
+int gmlrt_copy_rows_to_host(int device, const void* d_rows, void* image, size_t row_bytes, int64_t height,
+                            int32_t tile_rows, int32_t part, int32_t nparts) {
+  if (!d_rows || !image || row_bytes == 0 || height <= 0 || device < 0)
+    return fail(GMLRT_ERR_INVALID_ARG, "gmlrt_copy_rows_to_host: bad argument");
+  if (nparts > 1 && (tile_rows <= 0 || part < 0 || part >= nparts)) return fail(GMLRT_ERR_INVALID_ARG, "bad row partition");
+  return guarded([&]() -> int {
+    // (worker slots from 128 up: the in-process workers of gmlrt_render use the low ones)
+    std::string e = gmlrt::dev_copy_rows_to_host(128 + device, device, image, d_rows, row_bytes, height, tile_rows > 0 ? tile_rows : 8,
+                                                 nparts > 1 ? part : 0, nparts > 1 ? nparts : 1);
+    return e.empty() ? GMLRT_OK : fail(GMLRT_ERR_HIP, e);
   });
 }
 

@@ -1232,7 +1232,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (stats) {
     stats->rays_primary = stats->rays_shadow = stats->rays_reflect = stats->hits = 0;
     stats->kernel_ms = 0.0;
-    stats->leaf_tests = 0;
+    stats->reserved64 = 0;
   }
   if (rows == 0) return "";
 
@@ -1603,7 +1603,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->rays_reflect = counts[2];
     stats->hits = counts[3];
     stats->kernel_ms = (double)ms;
-    stats->leaf_tests = (counts[0] + counts[1] + counts[2]) * (uint64_t)H.n_leaves;
+    stats->reserved64 = 0;
     stats->surface_errors = *(const uint32_t*)((const uint8_t*)s->h_staging + 1024 - 8) ? 1u : 0u;
   }
   return "";

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GMLRT_LIB") or os.path.join(_HERE, "libgmlrt.so")  # 
 EXPORTS = [
     "gmlrt_strerror", "gmlrt_last_error", "gmlrt_part_rows", "gmlrt_part_row_index", "gmlrt_init",
     "gmlrt_shutdown", "gmlrt_device_count", "gmlrt_render", "gmlrt_scene_create", "gmlrt_scene_destroy",
-    "gmlrt_render_device", "gmlrt_render_device_noalloc", "gmlrt_render_to_sink", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
+    "gmlrt_render_device", "gmlrt_render_device_noalloc", "gmlrt_copy_rows_to_host", "gmlrt_render_to_sink", "gmlrt_write_ppm", "gmlrt_program_open_file", "gmlrt_program_open_text",
     "gmlrt_program_close", "gmlrt_program_num_renders", "gmlrt_program_render_call",
 ]
 
@@ -32,12 +32,12 @@ class Params(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("rays_primary", ctypes.c_uint64), ("rays_shadow", ctypes.c_uint64), ("rays_reflect", ctypes.c_uint64),
-                ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("leaf_tests", ctypes.c_uint64),
+                ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("reserved64", ctypes.c_uint64),
                 ("hits", ctypes.c_uint64), ("n_gpus", ctypes.c_uint32), ("surface_errors", ctypes.c_uint32)]
 
     def as_dict(self):
         return {"primary": self.rays_primary, "shadow": self.rays_shadow, "reflect": self.rays_reflect,
-                "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "leaf_tests": self.leaf_tests, "hits": self.hits,
+                "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "hits": self.hits,
                 "n_gpus": self.n_gpus, "surface_errors": self.surface_errors}
 
     @property
@@ -104,6 +104,7 @@ def lib():
         L.gmlrt_scene_destroy.restype = None
         L.gmlrt_render_device.argtypes = [vp, ctypes.POINTER(Params), vp, vp, vp, ctypes.POINTER(Stats)]
         L.gmlrt_render_device_noalloc.argtypes = L.gmlrt_render_device.argtypes
+        L.gmlrt_copy_rows_to_host.argtypes = [ctypes.c_int, vp, vp, sz, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.gmlrt_write_ppm.argtypes = [ctypes.c_char_p, vp, ctypes.c_int64, ctypes.c_int64]
         L.gmlrt_program_open_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
         L.gmlrt_program_open_text.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -242,6 +243,16 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+def copy_rows_to_host(device, d_rows_ptr, image, tile_rows, part, nparts):
+    """gmlrt_copy_rows_to_host: the packed rows at device pointer d_rows_ptr go to their places in `image`, a
+    C-contiguous numpy array [height, ...] in host memory (possibly a shared mapping)."""
+    assert image.flags["C_CONTIGUOUS"]
+    height = image.shape[0]
+    row_bytes = image.strides[0]
+    _check(lib().gmlrt_copy_rows_to_host(device, d_rows_ptr, image.ctypes.data_as(ctypes.c_void_p), row_bytes, height,
+                                         tile_rows, part, nparts), "gmlrt_copy_rows_to_host")
 
 
 def write_ppm(path, rgb8):

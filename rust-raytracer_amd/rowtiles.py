@@ -4,6 +4,9 @@ Image rows are independent (raytracer.rs:137-146), so a frame is cut into tiles 
 round-robin to the ranks (rank r renders tiles r, r+world, ...: cheap sky rows and expensive board rows are spread
 evenly).  Nothing is exchanged while rendering; the only collective is this gather of the finished rows to rank 0.
 """
+import os
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -39,3 +42,43 @@ def assemble(gathered, height, tile_rows):
         rows = torch.as_tensor(my_rows(height, tile_rows, r, world), device=frame.device)
         frame[rows] = gathered[r][: len(rows)]
     return frame
+
+
+class SharedFramebuffer:
+    """The frame as one host buffer that every rank of the node has mapped (a file in /dev/shm): the final gather
+    is then each rank copying the rows it rendered from its own GPU straight to their places, all ranks at once, each
+    over its own GPU's host link; no rank receives the others' rows first and nothing crosses the GPU-to-GPU links.
+    Rank 0 creates the file; everybody calls close() at the end (rank 0 removes the file)."""
+
+    def __init__(self, height, width, channels=3, dtype=np.uint8, tile_rows=8):
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.tile_rows = tile_rows
+        shape = (height, width, channels)
+        name = ["/dev/shm/gmlrt_fb_%d_%d" % (os.getpid(), int(os.environ.get("MASTER_PORT", "0")))] if self.rank == 0 else [None]
+        if self.rank == 0:
+            with open(name[0], "wb") as f:
+                f.truncate(int(np.prod(shape)) * np.dtype(dtype).itemsize)
+        if self.world > 1:
+            dist.broadcast_object_list(name, src=0)  # also orders the creation before everybody's open
+        self.path = name[0]
+        self.frame = np.memmap(self.path, dtype=dtype, mode="r+", shape=shape)
+
+    def put_rows_from_device(self, device, d_rows_ptr):
+        """This rank's packed rows (device memory) to their image positions."""
+        gmlrt.copy_rows_to_host(device, d_rows_ptr, self.frame, self.tile_rows, self.rank, self.world)
+
+    def put_rows_from_host(self, local):
+        """The same from a host array [rows, w, c] (CPU rehearsals of the multi-rank path)."""
+        rows = my_rows(self.frame.shape[0], self.tile_rows, self.rank, self.world)
+        self.frame[rows] = np.asarray(local)[: len(rows)]
+
+    def close(self):
+        if self.world > 1:
+            dist.barrier()
+        self.frame = None  # drops the mapping
+        if self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass

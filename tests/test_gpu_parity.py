@@ -427,6 +427,45 @@ def test_surface_run_time_errors_are_reported(gmlrt, oracle):
     assert st_ok.surface_errors == 0
 
 
+def test_rows_go_from_the_device_to_their_places_in_a_host_frame(gmlrt):
+    # gmlrt_copy_rows_to_host: the final gather of the one-process-per-GPU form, each partition on its own
+    import torch
+    call = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0].with_overrides(640, 203, 2)
+    full, full64, _ = gmlrt.render(call, want_f64=True)
+    h, w = call.params.height, call.params.width
+    scene = gmlrt.DeviceScene(call.blob, 0)
+    for nparts, tile_rows in [(1, 8), (2, 8), (3, 16), (8, 8)]:
+        frame = np.zeros((h, w, 3), np.uint8)
+        frame64 = np.zeros((h, w, 3), np.float64)
+        for part in range(nparts):
+            p = gmlrt.Params()
+            ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
+            p.tile_rows, p.part, p.nparts = tile_rows, part, nparts
+            n = gmlrt.part_rows(h, tile_rows, part, nparts)
+            d8 = torch.zeros((n, w, 3), dtype=torch.uint8, device="cuda:0")
+            d64 = torch.zeros((n, w, 3), dtype=torch.float64, device="cuda:0")
+            scene.render_into(p, d8.data_ptr(), d64.data_ptr())
+            gmlrt.copy_rows_to_host(0, d8.data_ptr(), frame, tile_rows, part, nparts)
+            gmlrt.copy_rows_to_host(0, d64.data_ptr(), frame64, tile_rows, part, nparts)
+        assert (frame == full).all() and (frame64 == full64).all(), (nparts, tile_rows)
+    scene.close()
+
+
+def test_two_ranks_share_a_host_framebuffer(gmlrt):
+    # the N > 1 form of bench.py on the one GPU there is: two ranks (gloo for the control messages, both on GPU 0),
+    # each renders its interleaved row tiles and copies them into the frame both have mapped; rank 0 checks the frame
+    import json, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "2", "--warmup", "1", "--width", "960", "--height", "540", "--verify"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["gather_ms_per_step"] is not None
+    assert line["config"]["rays_per_frame"] > 960 * 540
+
+
 def test_in_process_multi_gpu_path_on_one_gpu(gmlrt, monkeypatch):
     # gmlrt_render with the frame split into partitions (one host thread each, strided copies straight into the
     # caller's buffers); GMLRT_EMULATE_PARTS runs every partition on the GPU that is there

@@ -29,11 +29,17 @@ WORKER = textwrap.dedent("""
         img, _, _ = prog.render(0, w=W, h=H, depth=DEPTH, y0=int(y), y1=int(y) + 1)
         local[k] = torch.from_numpy(img[0])
     got = rowtiles.gather_to_rank0(local)
+    # the other form of the gather: a host framebuffer every rank has mapped, each rank puts its own rows
+    shared = rowtiles.SharedFramebuffer(H, W, 3, tile_rows=TILE)
+    shared.put_rows_from_host(local.numpy())
+    dist.barrier()
     if rank == 0:
         frame = rowtiles.assemble(got, H, TILE).numpy()
         assert frame.shape == full.shape and (frame == full).all(), "reassembled frame differs"
+        assert (np.array(shared.frame) == full).all(), "shared host framebuffer differs"
         assert sum(len(rowtiles.my_rows(H, TILE, r, world)) for r in range(world)) == H
         print("MULTIRANK_OK", world)
+    shared.close()
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -48,3 +54,19 @@ def test_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "MULTIRANK_OK 2" in out.stdout
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    # `python bench.py --gpus 2` with WORLD_SIZE unset must become two ranks (a child torch.distributed.run started
+    # before anything touches a GPU), never a silent one-GPU run; --dry-run stops after the roll call
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import json
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == [0, 1] and sum(line["rows_per_rank"]) == 2160
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a wrong line
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run", "--backend", "gloo"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 4" in (bad.stdout + bad.stderr)

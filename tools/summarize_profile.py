@@ -4,6 +4,8 @@ profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <name>_pm
 render_kernel launch + derived figures), <name>_bench.json and <name>_bench_under_rocprof.json.
 Usage: tools/summarize_profile.py <tag> <name>     e.g.  tools/summarize_profile.py r01b r01_final"""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import source_hash
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
@@ -38,16 +40,31 @@ for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
 c = {k: round(tot[k] / cnt[k], 1) for k in sorted(tot)}
 launches = max(cnt.values())
 cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+# executed f64 arithmetic: wave-instructions by class, an FMA counts two flops, times the mean number of lanes that
+# were active when a VALU instruction issued (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU)
+f64_insts = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+f64_flop_insts = f64_insts + c["SQ_INSTS_VALU_FMA_F64"]
+lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
+kernel_ms = sum(launch_ms[-5:]) / 5
 derived = {
     "gpu_cycles_per_launch": round(cycles),
-    "valu_busy_fraction": round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), 3),
-    "valu_busy_fraction_note": "SQ_INSTS_VALU x 4 cycles (a wave64 instruction occupies a 16-lane SIMD for 4 cycles) / (1024 SIMDs x cycles)",
+    "f64_valu_instructions_per_launch": round(f64_insts),
+    "f64_share_of_valu_instructions": round(f64_insts / c["SQ_INSTS_VALU"], 3),
+    "mean_active_lanes_per_valu_instruction": round(lanes, 2),
+    "f64_flops_per_launch": round(f64_flop_insts * lanes),
+    "f64_flops_note": "(ADD_F64 + MUL_F64 + TRANS_F64 + 2 x FMA_F64 wave-instructions) x mean active lanes; compares, selects, moves, conversions and min/max are not counted",
+    "f64_tflops_at_trace_kernel_time": round(f64_flop_insts * lanes / (kernel_ms * 1e-3) / 1e12, 3),
+    "valu_busy_fraction": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles), 3),
+    "valu_busy_fraction_note": "SQ_ACTIVE_INST_VALU (quad-cycles in which a wave executes a VALU instruction) x 4 / (1024 SIMDs x GPU cycles); "
+                               "no cost per instruction class is assumed. Per VALU instruction that is %.2f cycles on average "
+                               "(f64 arithmetic issues over 4 cycles for 64 lanes, 32-bit operations over 2 when a second wave can take the other slot)" % (c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"]),
     "salu_per_valu": round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 2),
     "fetch_bytes_per_launch": round(c["FETCH_SIZE"] * 1024),
     "write_bytes_per_launch": round(c["WRITE_SIZE"] * 1024),
     "traffic_note": "FETCH_SIZE/WRITE_SIZE are in KiB per dispatch (checked against a 24.9 MB fill kernel: WRITE_SIZE 24300). They count L2<->fabric requests, Infinity Cache hits included. The reads here are 8 B/lane, a width the guide calls uncalibrated; no doubling applied.",
 }
 json.dump({
+    "kernel_source_hash": source_hash(),
     "command": "rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)",
     "workload": "chess.gml 3840x2160 depth 5, 1 MI355X, per render_kernel launch (mean of the %d timed launches of each pass)" % launches,
     "kernel_trace": {
