@@ -28,9 +28,12 @@ struct ProgBound {   // 64 bytes
 struct ProgBox {     // 64 bytes: the same as ProgBound with the subtree's box instead of its sphere
   uint32_t kind;
   uint32_t skip_to;
-  double lo[3];
-  double hi[3];
-  uint64_t pad;
+  // The box in single precision, rounded outwards, as three (lo, hi) pairs, and per axis the larger magnitude
+  // of the two: the test runs in f32 with an explicit bound on its own rounding error (it only has to be
+  // conservative, never reproducible).
+  float lohi[6];     // lo.x hi.x lo.y hi.y lo.z hi.z
+  float mag[3];      // max(|lo|, |hi|) per axis, rounded up
+  uint32_t pad[5];
 };
 struct ProgLeaf {    // 128 bytes
   uint32_t kind;

@@ -158,7 +158,16 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
         r.kind = kRecBox | (frontier ? kRecFlag : 0u);
         // the slab test is symmetric in lo and hi, so an empty solid (lo > hi) is stated as a
         // point no ray of interest can reach
-        for (int i = 0; i < 3; i++) { r.lo[i] = empty ? 1e300 : g.lo[i]; r.hi[i] = empty ? 1e300 : g.hi[i]; }
+        for (int i = 0; i < 3; i++) {
+          const double lo = empty ? 1e30 : g.lo[i], hi = empty ? 1e30 : g.hi[i];
+          // to single precision, outwards (a value beyond the float range becomes +-infinity: "no information")
+          float flo = (float)lo, fhi = (float)hi;
+          if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+          if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+          r.lohi[2 * i] = flo;
+          r.lohi[2 * i + 1] = fhi;
+          r.mag[i] = std::nextafterf(std::max(std::fabs(flo), std::fabs(fhi)), INFINITY);
+        }
         return S.put(&r, sizeof(r));
       }
     }

@@ -48,8 +48,22 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
   uint32_t level = 0;    // operand stack depth (wave-uniform)
   const int tid = threadIdx.x;
   uint32_t pc = 0;       // byte offset of the current record (wave-uniform)
-  // for the box tests; a zero component gives +-inf, which the slab arithmetic below handles
-  const V3 inv_d = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
+  // For the box tests, in single precision: t = p * inv - o * inv for a slab plane p, one fused operation per
+  // plane.  Against the exact value the computed t is off by at most
+  //     E = 2^-21 * (|p| + |o|) * |inv|      (p rounded outwards to f32: 2^-23 relative; inv and o * inv rounded
+  //                                            to f32: 2^-24 each; the fused operation: 2^-24 of |t| <= (|p| + |o|) |inv|)
+  // and every slab interval is widened by the largest E of the three axes before the intervals are compared, so
+  // a ray that meets the box in exact arithmetic is never turned away.  A zero direction component gives
+  // inv = +-inf and t = NaN (inf - inf) or +-inf; min/max skip a NaN operand, which leaves that slab out, and a
+  // NaN or infinite E keeps the subtree: conservative in every case.
+  const double inv_dx = 1.0 / d.x, inv_dy = 1.0 / d.y, inv_dz = 1.0 / d.z;
+  const float inv_x = (float)inv_dx, inv_y = (float)inv_dy, inv_z = (float)inv_dz;
+  const float noi_x = -(float)(o.x * inv_dx), noi_y = -(float)(o.y * inv_dy), noi_z = -(float)(o.z * inv_dz);
+  constexpr float kErr = 4.76837158203125e-07f;  // 2^-21
+  const float ie_x = kErr * __builtin_fabsf(inv_x), ie_y = kErr * __builtin_fabsf(inv_y), ie_z = kErr * __builtin_fabsf(inv_z);
+  const float oe_x = __builtin_fabsf((float)o.x) * ie_x, oe_y = __builtin_fabsf((float)o.y) * ie_y, oe_z = __builtin_fabsf((float)o.z) * ie_z;
+// (the element is copied first: a bit cast applied directly to a vector element lvalue read element 0 whatever the index)
+#define REC_F32(i) __uint_as_float((uint32_t)R[2 + (i)])
   typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 #define REC_F64(i) __builtin_bit_cast(double, (uint64_t)R[2 + 2 * (i)] | ((uint64_t)R[3 + 2 * (i)] << 32))
   for (;;) {
@@ -73,17 +87,18 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       bool hit;
       uint32_t next;
       if (kind == kRecBox) {
-        // ProgBox: skip_to, lo[3], hi[3].  Slab test; fmin/fmax return the other operand when
-        // one is NaN (0 * inf: the ray runs inside a face plane), which leaves that slab out.
-        const double x1 = (REC_F64(0) - o.x) * inv_d.x, x2 = (REC_F64(3) - o.x) * inv_d.x;
-        const double y1 = (REC_F64(1) - o.y) * inv_d.y, y2 = (REC_F64(4) - o.y) * inv_d.y;
-        const double z1 = (REC_F64(2) - o.z) * inv_d.z, z2 = (REC_F64(5) - o.z) * inv_d.z;
-        const double tnear = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmax(fmin(z1, z2), 0.0));
-        const double tfar = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-        // the relative slack covers the rounding of the six products
-        hit = (fl & kFlActive) && !(tfar * (1.0 + 1e-9) < tnear)
+        // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
+        const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
+        const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
+        const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
+        const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
+                                          __builtin_fmaf(REC_F32(8), ie_z, oe_z));
+        const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+        const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+        const float tn_lo = tnear - err;  // no entry before this
+        hit = (fl & kFlActive) && !(tfar + err < tn_lo)
 #if GMLRT_TMAX_CULL
-              && !((best_m & kHitAny) && tnear > best)
+              && !((best_m & kHitAny) && (double)tn_lo > best)
 #endif
             ;
         next = pc + (uint32_t)sizeof(ProgBox);
@@ -227,6 +242,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     break;  // kRecEnd
   }
 #undef REC_F64
+#undef REC_F32
   h.any = (best_m & kHitAny) != 0;
   h.dist = best;
   h.meta = best_m & ~kHitAny;
