@@ -905,6 +905,13 @@ struct Flattener : gml::TreeVisitor {
       case gml::PrimType::Sphere: break;
       case gml::PrimType::Cube: lo[0] = lo[1] = lo[2] = 0.0; break;
       case gml::PrimType::Cylinder:
+        // The reference's cylinder reports hits slightly OUTSIDE the solid for rays within 1e-7 of parallel or
+        // orthogonal to the axis (primitives.rs:644-663 test only the ray's origin against the radius, or against
+        // the two caps, and let the ray drift from there).  The box is widened by a thousandth of the unit
+        // cylinder so that such a hit still lies inside it: that covers an orthogonal ray's drift along the axis
+        // over 10^4 object units and a parallel ray's sideways drift (4.5e-4 per unit) over two.
+        lo[0] = lo[2] = -1.001; hi[0] = hi[2] = 1.001; lo[1] = -0.001; hi[1] = 1.001;
+        break;
       case gml::PrimType::Cone: lo[1] = 0.0; break;
       default: return plane_bound(t);  // half-space: at best bounded on one side of one axis
     }

@@ -248,9 +248,24 @@ class Operator:
     def __init__(self, rule, a, b):
         self.rule, self.a, self.b = self.RULES[rule], a, b
 
+    # transforms are forwarded to both operands (primitives.rs:213-238)
+    def _both(self, name, *args):
+        getattr(self.a, name)(*args)
+        getattr(self.b, name)(*args)
+        return self
+
+    def translate(self, *a): return self._both("translate", *a)
+    def scale(self, *a): return self._both("scale", *a)
+    def uscale(self, *a): return self._both("uscale", *a)
+    def rotatex(self, *a): return self._both("rotatex", *a)
+    def rotatey(self, *a): return self._both("rotatey", *a)
+    def rotatez(self, *a): return self._both("rotatez", *a)
+
     def intersect(self, raypos, raydir):
         events = [(h, 1) for h in self.a.intersect(raypos, raydir)] + [(h, 2) for h in self.b.intersect(raypos, raydir)]
         events.sort(key=lambda e: e[0]["dist"])  # stable: ties keep obj1 before obj2
+        if len(events) > MAX_EVENTS_SEEN[0]:
+            MAX_EVENTS_SEEN[0] = len(events)
         in1 = in2 = 0
         inside = False
         prevt = 0.0
@@ -359,6 +374,172 @@ def build_mixed():
               Point((-2.0, 2.0, 1.0), (0.9, 0.8, 0.7)), Directional((1.0, -1.0, 0.5), (0.5, 0.5, 0.5))]
     return scene, lights
 
+
+# ---- a chess piece with its procedural surface, and the board, built by hand (gml/chess.gml:17-60, 76-104, 225-271)
+def gml_floor(x):
+    return int(math.floor(x))  # `f.floor() as i64` (evaluator.rs:388); the arguments here are far from the i64 range
+
+
+def gml_modi(a, b):
+    q = abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)  # Rust's `/` truncates towards zero (evaluator.rs:216-218)
+    return a - b * q
+
+
+def gml_asin_deg(x):
+    return math.asin(x) * (180.0 / math.pi)  # evaluator.rs:335-339: degrees
+
+
+def figure_surface(col1, col2):
+    """figureSurface of gml/chess.gml:28-43 written out in Python instead of being evaluated as GML."""
+    def surface(face, u, v):
+        if face == 0:  # rotational: stripes according to the angle u (radians: primitives.rs:403-412, 726-734)
+            col = col1 if gml_modi(gml_floor(u * 12.0), 2) == 1 else col2
+        else:          # flat: rays according to the angle from the centre to (u, v)
+            uu, vv = u - 0.5, v - 0.5
+            b = uu / math.sqrt(uu * uu + vv * vv)
+            a = gml_asin_deg(b) if 0.0 < vv else 360.0 - gml_asin_deg(b)
+            col = col1 if gml_modi(gml_floor((a + 180.0) / 30.0), 2) == 1 else col2
+        return (col, 0.7, 0.3, 1.0)
+    return surface
+
+
+def board_surface(face, u, v):
+    """gml/chess.gml:49-60."""
+    black1, white2 = (0.2, 0.2, 0.3), (1.0, 1.0, 0.8)
+    if 3 < face:
+        lhs, k = 0, gml_floor(u * 8.0) + gml_floor(v * 8.0)
+    else:
+        lhs, k = (0 if gml_modi(face, 2) == 0 else 1), gml_floor(u * 8.0)
+    return (black1 if lhs == gml_modi(k, 2) else white2, 0.4, 0.6, 0.5)
+
+
+TOWER_GML = """
+{ /y /x x x mulf y y mulf addf sqrt } /dist
+0.2 0.2 0.3 point /black1  0.4 0.4 0.5 point /black2  0.7 0.7 0.5 point /white1  1.0 1.0 0.8 point /white2
+{ /col2 /col1
+  { /v /u /face
+    face 0 eqi
+    { u 12.0 mulf floor 2 modi 1 eqi { col1 } { col2 } if }
+    { u 0.5 subf /u v 0.5 subf /v
+      u u v dist apply divf /b
+      0.0 v lessf { b asin } { 360.0 b asin subf } if 180.0 addf 30.0 divf
+      floor 2 modi 1 eqi { col1 } { col2 } if }
+    if
+    0.7 0.3 1.0 }
+} /figureSurface
+{ /v /u /face
+  3 face lessi
+  { 0 u 8.0 mulf floor v 8.0 mulf floor addi }
+  { face 2 modi 0 eqi { 0 } { 1 } if u 8.0 mulf floor } if 2 modi eqi { black1 } { white2 } if
+  0.4 0.6 0.5
+} cube -0.5 -1.0 -0.5 translate 8.0 0.3 8.0 scale /board
+{ /col2 /col1
+  col1 col2 figureSurface apply /surface
+  col1 col1 figureSurface apply /surface1
+  col2 col2 figureSurface apply /surface2
+  surface cylinder 1.0 0.75 1.0 scale
+  surface cone 0.0 -1.0 0.0 translate 180.0 rotatez 90.0 rotatey
+  1.0 7.5 1.0 scale union
+  surface cylinder 1.0 2.8 1.0 scale intersect
+  surface cylinder 0.0 3.0 0.0 translate union
+  surface cylinder 0.7 4.0 0.7 scale
+  { /rot
+    surface1 plane 90.0 rotatex
+    surface2 plane -90.0 rotatex 30.0 rotatey intersect rot rotatey
+  } /apex
+  15.0 apex apply 75.0 apex apply union 135.0 apex apply union
+  195.0 apex apply union 255.0 apex apply union 315.0 apex apply union
+  surface cylinder intersect union
+  0.0 3.5 0.0 translate difference
+  0.4 uscale
+} /tower
+white1 white2 tower apply /whiteTower
+black1 black2 tower apply /blackTower
+board
+whiteTower -1.5 0.0 -1.5 translate union
+blackTower 1.5 0.0 0.5 translate union
+30.0 rotatey -20.0 rotatex 0.4 uscale 0.3 0.0 3.0 translate /scene
+0.0 0.0 -1.0 point 1.0 1.0 1.0 point pointlight /l
+0.33 0.33 0.33 point [ l ] scene %d 60.0 %d %d "tower.ppm" render
+"""
+
+
+def build_towers():
+    """The scene of TOWER_GML built by hand: the board and two towers of gml/chess.gml (a piece of nested
+    intersections, unions and a difference whose operands share surfaces exactly: the base cylinder, the 2.8-high
+    cylinder and the wall cone's base all lie on x^2 + z^2 = 1; the platform's bottom coincides with the wall's cut)."""
+    black1, black2, white1, white2 = (0.2, 0.2, 0.3), (0.4, 0.4, 0.5), (0.7, 0.7, 0.5), (1.0, 1.0, 0.8)
+    ids = iter(range(1, 1000))
+
+    def tower(col1, col2):
+        surface, surface1, surface2 = figure_surface(col1, col2), figure_surface(col1, col1), figure_surface(col2, col2)
+        base = Leaf("cylinder", surface, next(ids)).scale(1.0, 0.75, 1.0)
+        wall = Leaf("cone", surface, next(ids)).translate(0.0, -1.0, 0.0).rotatez(180.0).rotatey(90.0).scale(1.0, 7.5, 1.0)
+        body = Operator("union", base, wall)
+        body = Operator("intersect", body, Leaf("cylinder", surface, next(ids)).scale(1.0, 2.8, 1.0))
+        body = Operator("union", body, Leaf("cylinder", surface, next(ids)).translate(0.0, 3.0, 0.0))
+        bore = Leaf("cylinder", surface, next(ids)).scale(0.7, 4.0, 0.7)
+
+        def apex(rot):
+            a = Leaf("plane", surface1, next(ids)).rotatex(90.0)
+            b = Leaf("plane", surface2, next(ids)).rotatex(-90.0).rotatey(30.0)
+            return Operator("intersect", a, b).rotatey(rot)
+
+        holes = apex(15.0)
+        for rot in (75.0, 135.0, 195.0, 255.0, 315.0):
+            holes = Operator("union", holes, apex(rot))
+        holes = Operator("intersect", holes, Leaf("cylinder", surface, next(ids)))
+        cut = Operator("union", bore, holes).translate(0.0, 3.5, 0.0)
+        return Operator("difference", body, cut).uscale(0.4)
+
+    board = Leaf("cube", board_surface, next(ids)).translate(-0.5, -1.0, -0.5).scale(8.0, 0.3, 8.0)
+    scene = Operator("union", Operator("union", board, tower(white1, white2).translate(-1.5, 0.0, -1.5)),
+                     tower(black1, black2).translate(1.5, 0.0, 0.5))
+    scene.rotatey(30.0).rotatex(-20.0).uscale(0.4).translate(0.3, 0.0, 3.0)
+    return scene, [Point((0.0, 0.0, -1.0), (1.0, 1.0, 1.0))]
+
+
+# ---- more than twenty events with pairwise equal distances in one operator
+TIES_GML = """
+{ /v /u /face 0.9 0.2 0.1 point 0.8 0.3 2.0 } /red
+{ /v /u /face 0.1 0.3 0.9 point 0.8 0.3 2.0 } /blue
+{ /v /u /face 0.2 0.8 0.2 point 1.0 0.0 1.0 } /green
+{ /s s sphere 0.45 uscale -2.5 0.0 0.0 translate
+  s sphere 0.45 uscale -1.5 0.0 0.0 translate union  s sphere 0.45 uscale -0.5 0.0 0.0 translate union
+  s sphere 0.45 uscale 0.5 0.0 0.0 translate union   s sphere 0.45 uscale 1.5 0.0 0.0 translate union
+  s sphere 0.45 uscale 2.5 0.0 0.0 translate union } /row
+red row apply blue row apply union
+green cube -0.5 -0.5 -0.5 translate 5.5 0.6 2.0 scale intersect
+90.0 rotatey 0.05 0.03 4.5 translate /scene
+1.0 -1.0 1.0 point 1.0 1.0 1.0 point light /l
+0.3 0.3 0.3 point [ l ] scene 2 60.0 %d %d "ties.ppm" render
+"""
+
+
+def build_ties():
+    """The scene of TIES_GML: two rows of six spheres that coincide sphere for sphere (one row red, one blue), united,
+    then cut by a slab.  A ray along the rows meets up to 24 events in the union node, every distance twice: which of
+    two events at the same distance comes first decides whose surface is shaded.  This code, the oracle and the device
+    all take the sort of primitives.rs:271 (`sort_unstable_by`) to keep the order obj1-before-obj2 on ties, which is
+    what Rust's insertion sort does for at most 20 elements; for longer lists Rust leaves the order unspecified."""
+    red = lambda face, u, v: ((0.9, 0.2, 0.1), 0.8, 0.3, 2.0)
+    blue = lambda face, u, v: ((0.1, 0.3, 0.9), 0.8, 0.3, 2.0)
+    green = lambda face, u, v: ((0.2, 0.8, 0.2), 1.0, 0.0, 1.0)
+    ids = iter(range(1, 100))
+
+    def row(surface):
+        node = Leaf("sphere", surface, next(ids)).uscale(0.45).translate(-2.5, 0.0, 0.0)
+        for x in (-1.5, -0.5, 0.5, 1.5, 2.5):
+            node = Operator("union", node, Leaf("sphere", surface, next(ids)).uscale(0.45).translate(x, 0.0, 0.0))
+        return node
+
+    both = Operator("union", row(red), row(blue))
+    slab = Leaf("cube", green, next(ids)).translate(-0.5, -0.5, -0.5).scale(5.5, 0.6, 2.0)
+    scene = Operator("intersect", both, slab).rotatey(90.0).translate(0.05, 0.03, 4.5)
+    return scene, [Directional((1.0, -1.0, 1.0), (1.0, 1.0, 1.0))]
+
+
+MAX_EVENTS_SEEN = [0]
 
 COUNTS = {"primary": 0, "shadow": 0, "reflect": 0}
 

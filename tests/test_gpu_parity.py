@@ -396,6 +396,20 @@ def test_renderer_sink_streams_an_8k_frame_without_holding_it(gmlrt, helpers):
     assert state.first_pixel_ns / 1e6 < 0.5 * st.total_ms
 
 
+def test_hand_checked_scenes_of_the_independent_restatement(gmlrt, oracle):
+    # the scenes tests/independent_render.py builds by hand (and tests/test_oracle_kats.py pins the oracle with):
+    # two chess towers on the board, and two coinciding rows of spheres whose union meets 24 events with pairwise
+    # equal distances (long lists: the general merge, ties, the swapped-operand intersection)
+    import independent_render as ind
+    for text in (ind.TOWER_GML % (3, 320, 240), ind.TIES_GML % (320, 160), ind.MIXED_GML % (200, 150)):
+        img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+        ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+        frac1, maxd, ndiff = image_diff(img, ref)
+        assert ndiff == 0, (ndiff, maxd)
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+        assert np.abs(f64 - ref64).max() <= 1e-9
+
+
 def test_surface_run_time_errors_are_reported(gmlrt, oracle):
     # evaluator.rs:357 / 544-555: `divi` by zero and `get` out of range abort the reference inside a surface call.
     # The device cannot abort; it delivers the image (0 / first element in place of the failed operation) and the

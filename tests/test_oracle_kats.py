@@ -193,3 +193,40 @@ def test_independent_python_restatement_all_primitives_rules_and_lights(oracle):
     assert (raw == ref64).all()
     assert (got == ref).all()
     assert cnt["shadow"] > 0 and cnt["reflect"] > 0 and len(np.unique(got)) > 50
+
+
+def test_independent_python_restatement_chess_towers_with_surface_written_in_python(oracle):
+    # two towers of gml/chess.gml on its board, nested union / intersect / difference with exactly shared surfaces
+    # (gml/chess.gml:76-104), the procedural figureSurface and the board's checker written directly in Python
+    # (gml/chess.gml:28-60) instead of going through any GML evaluator: front-end errors that the oracle and the
+    # product would share (a transform builder, `modi`, `asin`, the order of operands) show up here
+    import independent_render as ind
+    w, h, depth = 120, 90, 3
+    img, raw, cnt = ind.render(ind.build_towers, w, h, depth, 60.0, (0.33, 0.33, 0.33))
+    ref, ref64, ref_cnt = oracle.OracleProgram(text=ind.TOWER_GML % (depth, w, h)).render(0, want_f64=True, threads=4)
+    got, raw = np.array(img, dtype=np.uint8), np.array(raw)
+    print("differing bytes", int((got != ref).sum()), "max |f64 diff|", float(np.abs(raw - ref64).max()), cnt)
+    assert cnt == {k: ref_cnt[k] for k in ("primary", "shadow", "reflect")}
+    assert (raw == ref64).all() and (got == ref).all()
+    assert cnt["reflect"] > 2000 and len(np.unique(got.reshape(-1, 3), axis=0)) > 100
+
+
+def test_tie_order_assumed_stable_obj1_first_also_beyond_twenty_events(oracle):
+    # 24 events in one operator, every distance twice (two coinciding rows of spheres): the first of two tied
+    # events decides whose colour a pixel gets.  The order-preserving sort is an ASSUMPTION about the reference's
+    # `sort_unstable_by` (primitives.rs:271) that holds for Rust's insertion sort up to 20 elements; beyond that the
+    # reference's order is unspecified.  What is checked here is that the three restatements share that one rule.
+    import independent_render as ind
+    w, h = 120, 60
+    ind.MAX_EVENTS_SEEN[0] = 0
+    img, raw, cnt = ind.render(ind.build_ties, w, h, 2, 60.0, (0.3, 0.3, 0.3))
+    assert ind.MAX_EVENTS_SEEN[0] > 20
+    ref, ref64, ref_cnt = oracle.OracleProgram(text=ind.TIES_GML % (w, h)).render(0, want_f64=True, threads=4)
+    got = np.array(img, dtype=np.uint8)
+    assert cnt == {k: ref_cnt[k] for k in ("primary", "shadow", "reflect")}
+    assert (np.array(raw) == ref64).all() and (got == ref).all()
+    # obj1 (the red row) wins every tie: no blue pixel anywhere, although the blue row is all there
+    rgb = got.astype(np.int32)
+    reddish = (rgb[..., 0] > rgb[..., 2] + 40).sum()
+    bluish = (rgb[..., 2] > rgb[..., 0] + 40).sum()
+    assert reddish > 50 and bluish == 0
