@@ -136,6 +136,9 @@ struct ShadeArgs {
   const SurfInstr* surf_prog;  // expanded surface programs
   unsigned long long* diag_waves;  // diagnostic build only: 8 counters per wave
   uint32_t* surf_error;        // set to 1 by a lane whose own surface program raised GMLRT_SOP_TRAP
+  double* ctx;                 // context records of all waves (wave-major, then field, then lane)
+  uint32_t vm_lds_off;         // byte offset of the block's register / hot-context region in its LDS
+  uint32_t pad2;
 };
 
 static_assert(sizeof(ShadeArgs) <= kOffSurfError - kOffShadeArgs, "ShadeArgs outgrew its slot in the counter buffer");
@@ -527,12 +530,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const uint8_t* __restrict__ prog, const ShadeArgs* __restrict__ shade_args, const KArgs A) {
   extern __shared__ __align__(16) uint16_t lens[];
   const int tid = threadIdx.x;
-  uint64_t* vm_fast = (uint64_t*)((uint8_t*)lens + A.vm_lds_off) + tid;
   const int lane = tid & (kWave - 1);
   const size_t wave = (size_t)blockIdx.x * (kBlock / kWave) + (size_t)(tid / kWave);
   double* __restrict__ evD = A.ev_dist + wave * A.ev_cap * kWave + lane;
   uint32_t* __restrict__ evM = A.ev_meta + wave * A.ev_cap * kWave + lane;
-  double* __restrict__ ctx = A.ctx + wave * A.ctx_fields * kWave + lane;
 
   LaneState S;
   S.o = {0, 0, 0};
@@ -540,6 +541,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   S.t_stop = -__builtin_inff();
   S.pix = 0;
   S.st = kIdle;
+  // ray counts of the whole wave, kept as scalars (a per-lane count would be one more vector register to
+  // save around every call of the per-ray code)
   uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
   // Pixels are handed out in 8x8 tiles.  A wave owns one tile at a time and feeds
   // its idle lanes from it, so the rays a wave traverses together stay close on
@@ -637,12 +640,13 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           S.t_stop = -__builtin_inff();
           S.st = kView;  // level 0
           S.pix = yl * (uint32_t)A.w + x;
-          n_primary++;
         }
       }
       tile_base += take;
       tile_left -= take;
-      idle = __ballot(st_kind(S.st) == kIdle);  // lanes that drew a padding slot are still idle
+      const unsigned long long idle_now = __ballot(st_kind(S.st) == kIdle);  // lanes that drew a padding slot are still idle
+      n_primary += (uint32_t)__popcll(idle & ~idle_now);
+      idle = idle_now;
     }
     if (!__ballot(st_kind(S.st) != kIdle)) break;  // nothing in flight and nothing left to hand out
     DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
@@ -664,27 +668,20 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- then the per-ray bookkeeping, out of line
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;
          dg.k_trav[dk]++; dg.k_leaf[dk] += dg.n_leaf - dk_leaf0;)
+    uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
     if (st_kind(S.st) != kIdle) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
-      uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
-      S = after_traversal<kLdsCtx>(S, h.dist, hm, shade_args, ctx, vm_fast, &events);
-      n_shadow += (events >> 24) & 1u;
-      n_reflect += (events >> 25) & 1u;
-      n_hits += (events >> 26) & 1u;
+      S = after_traversal<kLdsCtx>(S, h.dist, hm, shade_args, &events);
     }
+    n_shadow += (uint32_t)__popcll(__ballot((events & kStShadow) != 0));
+    n_reflect += (uint32_t)__popcll(__ballot((events & kStReflect) != 0));
+    n_hits += (uint32_t)__popcll(__ballot((events & kStHit) != 0));
     DIAG(t0 = __builtin_readcyclecounter(); dg.t_after += t0 - t2;)
   }
 
   if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(wall_clock64() - tile_t0);
 
-  // ---- ray counters: per wave ...
-  for (int off = 32; off > 0; off >>= 1) {
-    n_primary += (uint32_t)__shfl_down((int)n_primary, off);
-    n_shadow += (uint32_t)__shfl_down((int)n_shadow, off);
-    n_reflect += (uint32_t)__shfl_down((int)n_reflect, off);
-    n_hits += (uint32_t)__shfl_down((int)n_hits, off);
-  }
-  // ... summed over the block (in the first bytes of the operand-stack lengths, each wave in the slots of
+  // ---- ray counters of the waves, summed over the block (in the first bytes of the operand-stack lengths, each wave in the slots of
   // its own lanes: the other waves may still be tracing) and stored per block; the host adds the blocks
   // up.  Atomics on four device-wide counters, one set per wave, took 0.24 ms of every launch.
   {
@@ -1407,6 +1404,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.leaf_surf = (const uint32_t*)s->d_leaf_surf;
   SA.surf_prog = (const SurfInstr*)s->d_surf;
   SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
+  SA.ctx = A.ctx;
+  SA.vm_lds_off = A.vm_lds_off;
 #ifdef GMLRT_DIAG
   unsigned long long* d_diag_waves = nullptr;
   HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long)));

@@ -37,11 +37,17 @@ __device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD
 // Without that it saves and restores every callee-saved register it touches, about fifty
 // VGPRs to scratch memory and three dozen SGPRs, on every call; with it the caller spills
 // only the handful of values it really keeps across the call.
+//
+// The lane's context record and its slice of the block's LDS region are found from the thread's own position
+// (ShadeArgs has the bases): as arguments they would be four more registers, and arguments beyond what the
+// calling convention passes in registers travel through scratch memory at every call.
 template <bool kLds>
 __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
-                                                  const ShadeArgs* __restrict__ SA_v, double* __restrict__ ctx_v,
-                                                  uint64_t* __restrict__ vm_fast_v, uint32_t* __restrict__ events_out) {
+                                                  const ShadeArgs* __restrict__ SA_v, uint32_t* __restrict__ events_out) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
+  extern __shared__ __align__(16) uint16_t lens[];
+  uint64_t* const vm_fast_v = (uint64_t*)((uint8_t*)lens + SA->vm_lds_off) + threadIdx.x;
+  double* const ctx_v = SA->ctx + ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * SA->ctx_fields * kWave + (threadIdx.x & (kWave - 1));
   double* __restrict__ ctx = global_space(ctx_v);
   constexpr size_t kHotStride = kLds ? (size_t)kBlock : (size_t)kWave;
   double* hot;
