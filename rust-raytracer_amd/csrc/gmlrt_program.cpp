@@ -483,6 +483,19 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
                  items.size(), cost_given, cost, regroup ? "regrouped" : "as given");
   if (!regroup) S.bytes.swap(given);
   put_small(kRecEnd, 0);
+  if (std::getenv("GMLRT_VERBOSE")) {
+    size_t n_kind[8] = {0};
+    for (size_t at = 0; at + 16 <= S.bytes.size();) {
+      uint32_t kind;
+      std::memcpy(&kind, S.bytes.data() + at, 4);
+      const uint32_t k = kind & 0xFu;
+      n_kind[k & 7]++;
+      if (k == kRecEnd) break;
+      at += k == kRecLeaf ? sizeof(ProgLeaf) : (k == kRecBound || k == kRecBox) ? sizeof(ProgBound) : sizeof(ProgSmall);
+    }
+    std::fprintf(stderr, "[gmlrt] program: %zu bytes; records: %zu boxes, %zu spheres, %zu leaves, %zu operators, %zu skip-if-empty, %zu takes\n",
+                 S.bytes.size(), n_kind[kRecBox], n_kind[kRecBound], n_kind[kRecLeaf], n_kind[kRecOp], n_kind[kRecSkipEmpty], n_kind[kRecTake]);
+  }
   S.bytes.resize(S.bytes.size() + 64, 0);  // the traversal reads 64 bytes at every record, the last one included
   if (S.bytes.size() >= 0xFFFFFFF0ull) throw std::runtime_error("derived program too large");
   return S.bytes;
