@@ -176,7 +176,10 @@ def main():
     if world > 1 and args.gather == "rccl":
         gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
     elif world > 1:
-        shared = rowtiles.SharedFramebuffer(h, w, 3, tile_rows=TILE_ROWS)
+        try:
+            shared = rowtiles.SharedFramebuffer(h, w, 3, tile_rows=TILE_ROWS)
+        except RuntimeError:  # raised on every rank alike: fall back to the collective
+            gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
     gather_s = [0.0]
 

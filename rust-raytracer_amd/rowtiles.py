@@ -55,12 +55,19 @@ class SharedFramebuffer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.tile_rows = tile_rows
         shape = (height, width, channels)
-        name = ["/dev/shm/gmlrt_fb_%d_%d" % (os.getpid(), int(os.environ.get("MASTER_PORT", "0")))] if self.rank == 0 else [None]
+        name = [None]
         if self.rank == 0:
-            with open(name[0], "wb") as f:
-                f.truncate(int(np.prod(shape)) * np.dtype(dtype).itemsize)
+            try:
+                path = "/dev/shm/gmlrt_fb_%d_%d" % (os.getpid(), int(os.environ.get("MASTER_PORT", "0")))
+                with open(path, "wb") as f:
+                    f.truncate(int(np.prod(shape)) * np.dtype(dtype).itemsize)
+                name = [path]
+            except OSError:
+                name = [None]  # no shared memory file system here: every rank learns it below and raises alike
         if self.world > 1:
             dist.broadcast_object_list(name, src=0)  # also orders the creation before everybody's open
+        if name[0] is None:
+            raise RuntimeError("no shared host memory for the framebuffer (/dev/shm not writable)")
         self.path = name[0]
         self.frame = np.memmap(self.path, dtype=dtype, mode="r+", shape=shape)
 

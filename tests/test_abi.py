@@ -233,3 +233,16 @@ def test_sink_entry_point_rejects_bad_arguments(gmlrt):
     assert L.gmlrt_render_to_sink(c.blob, len(c.blob), ctypes.byref(c.params), b"x.ppm", None, None) == -1
     empty = gmlrt.Renderer()
     assert L.gmlrt_render_to_sink(c.blob, len(c.blob), ctypes.byref(c.params), b"x.ppm", ctypes.byref(empty), None) == -1
+
+
+def test_committed_counters_belong_to_these_kernel_sources():
+    # bench.py replays the executed-flop count of profiles/r02_final_pmc_summary.json only while the kernel sources
+    # hash to what the summary records; a kernel edit without a new profile round would silently drop the roofline
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")))
+    assert doc["kernel_source_hash"] == source_hash(), "kernel sources changed: run tools/profile_round.sh + tools/summarize_profile.py"
+    d = doc["derived"]
+    assert 0 < d["f64_flops_per_launch"] / (3.6e-3) / 1e12 / 78.6 < 1
