@@ -78,49 +78,31 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     // the wave reads next: they get a loop of their own, whose only state is scalar.  (In one loop
     // with the other record kinds every bound record paid for copying the lanes' candidate, flags
     // and stack height from one iteration to the next.)
-    while (kind == kRecBox || kind == kRecBound) {
+    while (kind == kRecBox) {
       // A bound in front of a subtree: if no lane's ray comes near it, every list below is
       // empty.  Under the union frontier that means "nothing to take"; inside a frontier
       // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
       // not reproducible, so they use fused multiply-adds.  Any NaN compares false and keeps
-      // the subtree.
-      bool hit;
-      uint32_t next;
-      if (kind == kRecBox) {
-        // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
-        const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
-        const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
-        const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
-        const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
-                                          __builtin_fmaf(REC_F32(8), ie_z, oe_z));
-        const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
-        const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
-        const float tn_lo = tnear - err;  // no entry before this
-        hit = (fl & kFlActive) && !(tfar + err < tn_lo)
+      // the subtree.  (Boxes are nearly all the bounds there are: the loop holds nothing else.)
+      // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
+      const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
+      const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
+      const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
+      const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
+                                        __builtin_fmaf(REC_F32(8), ie_z, oe_z));
+      const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+      const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+      const float tn_lo = tnear - err;  // no entry before this
+      const bool hit = (fl & kFlActive) && !(tfar + err < tn_lo)
 #if GMLRT_TMAX_CULL
-              && !((best_m & kHitAny) && (double)tn_lo > best)
+                       && !((best_m & kHitAny) && (double)tn_lo > best)
 #endif
-            ;
-        next = pc + (uint32_t)sizeof(ProgBox);
-      } else {
-        // ProgBound: skip_to, center[3], radius2, radius.  |perp|^2 = |oc|^2 - tca^2 (d has
-        // unit length); the slack added to r^2 covers the cancellation in that difference.
-        const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
-        const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
-        const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
-        const double r2 = REC_F64(3);
-        hit = (fl & kFlActive) && !(__builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2)) && !(tca < 0.0 && oc2 > r2)
-#if GMLRT_TMAX_CULL
-              && !((best_m & kHitAny) && tca - REC_F64(4) > best)
-#endif
-            ;
-        next = pc + (uint32_t)sizeof(ProgBound);
-      }
+          ;
       DIAG(dg.n_bound++;)
       DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
       if (__ballot(hit)) {
         DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(__ballot(hit));)
-        pc = next;
+        pc += (uint32_t)sizeof(ProgBox);
       } else {
         DIAG(dg.n_skip++;)
         if (!(kf & kRecFlag)) {
@@ -132,6 +114,33 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       R = *(const u32x16*)(const void*)(prog + pc);
       kf = R[0];
       kind = kf & 0xFu;
+    }
+    if (kind == kRecBound) {
+      // the same with the subtree's sphere.  ProgBound: skip_to, center[3], radius2, radius.  |perp|^2 =
+      // |oc|^2 - tca^2 (d has unit length); the slack added to r^2 covers the cancellation in that difference.
+      const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
+      const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
+      const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
+      const double r2 = REC_F64(3);
+      const bool hit = (fl & kFlActive) && !(__builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2)) && !(tca < 0.0 && oc2 > r2)
+#if GMLRT_TMAX_CULL
+                       && !((best_m & kHitAny) && tca - REC_F64(4) > best)
+#endif
+          ;
+      DIAG(dg.n_bound++;)
+      DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
+      if (__ballot(hit)) {
+        DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(__ballot(hit));)
+        pc += (uint32_t)sizeof(ProgBound);
+      } else {
+        DIAG(dg.n_skip++;)
+        if (!(kf & kRecFlag)) {
+          lens[level * kBlock + tid] = 0;
+          level++;
+        }
+        pc = R[1];
+      }
+      continue;
     }
     if (kind == kRecLeaf) {
       // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
