@@ -177,7 +177,7 @@ typedef struct gmlrt_stats {
   uint64_t rays_reflect; /* one per hit with ks > 0 && depth > 0 (raytracer.rs:100)  */
   double kernel_ms;      /* device time of the render kernel (HIP events; max over GPUs) */
   double total_ms;       /* host wall time of the call                               */
-  uint64_t reserved64;   /* 0                                                        */
+  uint64_t tiles_shared; /* 8x8-pixel tiles of this launch that four waves rendered together (0 on most launches) */
   uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
   uint32_t surface_errors; /* non-zero: some shaded hit raised GMLRT_SOP_TRAP (the call returns GMLRT_ERR_SURFACE) */

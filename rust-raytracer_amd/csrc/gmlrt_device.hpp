@@ -50,7 +50,10 @@ struct ProgSmall {   // 16 bytes: operator (arg = rule | kOpSwapped), take, end,
 static_assert(sizeof(ProgBox) == 64 && offsetof(ProgBox, skip_to) == offsetof(ProgBound, skip_to) && sizeof(ProgBound) == 64 && sizeof(ProgLeaf) == 128 && sizeof(ProgSmall) == 16, "record sizes");
 // need_stack / need_events: operand-stack levels and event slots per ray this program's evaluation order can
 // reach (it may differ from the blob's postfix order, for which the blob header states them).
-std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events);
+// slice_off[kProgSlices]: byte offsets of the frontier's slices, programs of their own behind the main one for
+// the waves of a block that trace the same rays together (all zero: the scene has no frontier worth slicing).
+constexpr uint32_t kProgSlices = 4;
+std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events, uint32_t* slice_off);
 // Expanded surface programs (SurfInstr records, gmlrt_surface_vm.h): every leaf's program
 // specialised for each face its primitive can report, identical results stored once;
 // leaf_surf[leaf * kSurfFaces + face] = index of the first record of the program to run for a
@@ -67,6 +70,7 @@ struct DeviceScene {
   size_t blob_bytes = 0;
   void* d_prog = nullptr;       // derived program (record stream)
   uint32_t n_prog = 0;          // its size in bytes
+  uint32_t slice_off[kProgSlices] = {0, 0, 0, 0};  // where the frontier's slices start in it (zeros: none)
   uint32_t max_stack = 1;       // operand-stack levels / event slots per ray: the larger of what the blob states for its
   uint64_t max_events = 2;      // postfix order (full-list traversal) and what the derived program's order needs
   uint32_t n_vm_regs = 0;       // registers the scene's surface bytecode uses
@@ -88,14 +92,21 @@ struct DeviceScene {
   size_t tiles_alloc = 0;
   bool order_valid = false;     // d_tile_order holds an order for order_key
   bool learn_order = true;      // false for a handle that renders once: learning would never pay
-  // Three ways of handing out the tiles: 0 image order, fixed small batches; 1 the learnt order with its batch
-  // table; 2 image order with a batch table of its own.  order_state counts the launches with this geometry:
-  // 0 nothing learnt (runs way 0 and times its tiles), 1 and 2: ways 1 and 2 on trial, 3: decided (order_way).
+  // Four ways of handing out the tiles: 0 image order, fixed small batches; 1 the learnt order with its batch
+  // table; 2 image order with a batch table of its own; 3 the learnt order with the dearest tiles taken out and
+  // rendered first, each by the four waves of a block together (only when the launch has tiles dear enough to set
+  // its length).  order_state counts the launches with this geometry: 0 nothing learnt (runs way 0 and times its
+  // tiles), 1, 2, 3: that way on trial, 4: decided (order_way).
   int order_state = 0;
-  int order_way = 0;            // the fastest of the three (a trial has to beat way 0 by 2 %)
-  float order_ms[3] = {0.f, 0.f, 0.f};  // kernel time of the launch that ran each way
+  int order_way = 0;            // the fastest of them (a trial has to beat way 0 by 2 %)
+  float order_ms[4] = {0.f, 0.f, 0.f, 0.f};  // kernel time of the launch that ran each way
   void* d_tile_batch_img = nullptr;      // way 2's batch table
   uint32_t n_batches_img = 0;
+  void* d_tile_order_rest = nullptr;     // way 3: order and batch table of the tiles that are not shared, and the shared ones
+  void* d_tile_batch_rest = nullptr;
+  void* d_tiles_shared = nullptr;
+  uint32_t n_batches_rest = 0, n_tiles_shared = 0;
+  std::vector<uint32_t> learnt_cost;     // verbose runs only: the costs the tables were made from
   gmlrt_params order_key{};     // the launch parameters the order belongs to (ambient zeroed)
   void* h_staging = nullptr;    // page-locked host memory for the launch record and the per-block ray counts
   int dev_cus = 0;              // device facts, asked once: compute units, LDS per block and per unit,

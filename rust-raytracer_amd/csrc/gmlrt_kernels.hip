@@ -110,6 +110,12 @@ struct KArgs {
   unsigned long long* tile_dbg;  // diagnostic build only: per tile, 4 counters
   unsigned long long* leaf_dbg;  // diagnostic build only: per leaf: tests, tests without an Entry in any lane, lanes with an Entry
   uint32_t* tile_cost;         // per tile: how long its wave spent on it (wall-clock ticks); null: not wanted
+  // Tiles that set the length of a launch are rendered first, each by the four waves of a block together: block b
+  // takes entries b, b + gridDim, ... of this list before it joins the ordinary hand-out.  slice_off: where the
+  // program slice of each wave of the block starts.
+  const uint32_t* tiles_shared;
+  uint32_t n_tiles_shared;
+  uint32_t slice_off[kProgSlices];
   unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
   unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
@@ -523,7 +529,9 @@ __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 #endif
 // kLdsCtx: the block's LDS has room for the hot fields of the shading context (see gmlrt_shade.hpp);
 // a kernel per case, so that the loop below holds a single call site of after_traversal.
-template <bool kLdsCtx>
+// kShared: the launch has tiles that the waves of a block render together (needs the LDS context region); a kernel of its own, so that
+// the ordinary one carries none of that.
+template <bool kLdsCtx, bool kShared>
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
@@ -565,10 +573,63 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   DIAG(unsigned long long t0 = __builtin_readcyclecounter(); const unsigned long long w_start = wall_clock64();
        unsigned long long w_tiles = 0;)
 
+  // slot `in` of an 8x8 tile -> pixel of this partition's packed rows -> camera ray in S (the lane stays idle on a padding slot).
+  // (Text, not a lambda: as a lambda the ordinary kernel came out with three more spilled registers.)
+#define GMLRT_CAMERA_RAY(tile_, in_)                                                                               \
+  do {                                                                                                             \
+    const uint32_t ct_ = (tile_), ci_ = (in_);                                                                     \
+    const uint32_t x = (ct_ % A.tiles_x) * kTileW + (ci_ % kTileW);                                                \
+    const uint32_t yl = (ct_ / A.tiles_x) * kTileH + (ci_ / kTileW);                                               \
+    if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {                                                         \
+      const uint32_t yp = yl + (uint32_t)A.band_row0; /* packed row of the partition */                            \
+      uint32_t y = yp;                                                                                             \
+      if (A.nparts > 1) {                                                                                          \
+        const uint32_t k = yp / (uint32_t)A.tile_rows;                                                             \
+        y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yp % (uint32_t)A.tile_rows;      \
+      }                                                                                                            \
+      /* raytracer.rs:138-142 */                                                                                   \
+      const double xf = (double)x, yf = (double)y;                                                                 \
+      V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};                                        \
+      S.o = {0.0, 0.0, -1.0};                                                                                      \
+      S.d = vnormalize(dir);                                                                                       \
+      S.t_stop = -__builtin_inff();                                                                                \
+      S.st = kView; /* level 0 */                                                                                  \
+      S.pix = yl * (uint32_t)A.w + x;                                                                              \
+    }                                                                                                              \
+  } while (0)
+  // Shared tiles: the four waves of the block hold the SAME 64 rays, each walks its own slice of the frontier,
+  // wave 0 keeps the nearest of the four candidates per ray, runs the per-ray code and hands the next rays to the
+  // other three.  A tile takes about a third of the time that way; the hand-out gives such treatment to the few
+  // tiles whose cost would otherwise set the length of the launch.  Everything that decides control flow here is
+  // the same in all four waves (the list position, and ray states that are copies of wave 0's), so the block's
+  // barriers are met by all of them.  The exchange goes through the hot-context slots of the lanes of waves 1-3,
+  // which hold nothing while those waves run no per-ray code: field f of thread t is xq[f * 256 + t].
+  const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane(tid / kWave);
+  uint32_t shared_next = blockIdx.x;
+  bool shared = false;
+  uint32_t pc0 = 0, shared_tile = 0;
+  [[maybe_unused]] double* const xq = (double*)((uint8_t*)lens + A.vm_lds_off);
+
   for (;;) {
     // ---- hand new pixels to idle lanes
     unsigned long long idle = __ballot(st_kind(S.st) == kIdle);
-    while ((uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more)) {
+    if constexpr (kShared) {
+      if ((shared || shared_next < A.n_tiles_shared) && idle == ~0ull) {
+        if (shared && A.tile_cost && tid == 0) A.tile_cost[shared_tile] = (uint32_t)(wall_clock64() - tile_t0);
+        shared = shared_next < A.n_tiles_shared;
+        pc0 = 0;
+        if (shared) {
+          shared_tile = A.tiles_shared[shared_next];
+          if (A.tile_cost) tile_t0 = wall_clock64();
+          GMLRT_CAMERA_RAY(shared_tile, (uint32_t)lane);
+          shared_next += gridDim.x;
+          pc0 = A.slice_off[wib];
+          idle = __ballot(st_kind(S.st) == kIdle);
+          if (wib == 0) n_primary += (uint32_t)__popcll(~idle);
+        }
+      }
+    }
+    while (!shared && (uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more)) {
       if (tile_left == 0) {
         bool none = false;
         if (batch_pos == batch_end) {
@@ -619,36 +680,17 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       const uint32_t want = (uint32_t)__popcll(idle);
       const uint32_t take = want < tile_left ? want : tile_left;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-      if (st_kind(S.st) == kIdle && rank < take) {
-        // slot -> 8x8 tile -> pixel of this partition's packed rows
-        const uint32_t slot = tile_base + rank;
-        const uint32_t tile = cur_tile, in = slot & 63u;
-        const uint32_t x = (tile % A.tiles_x) * kTileW + (in % kTileW);
-        const uint32_t yl = (tile / A.tiles_x) * kTileH + (in / kTileW);
-        if (x < (uint32_t)A.w && yl < (uint32_t)A.rows_part) {
-          const uint32_t yp = yl + (uint32_t)A.band_row0;  // packed row of the partition
-          uint32_t y = yp;
-          if (A.nparts > 1) {
-            const uint32_t k = yp / (uint32_t)A.tile_rows;
-            y = ((uint32_t)A.part + k * (uint32_t)A.nparts) * (uint32_t)A.tile_rows + yp % (uint32_t)A.tile_rows;
-          }
-          // raytracer.rs:138-142
-          const double xf = (double)x, yf = (double)y;
-          V3 dir = {A.c_x + (xf + 0.5) * A.pw, A.c_y - (yf + 0.5) * A.pw, 1.0};
-          S.o = {0.0, 0.0, -1.0};
-          S.d = vnormalize(dir);
-          S.t_stop = -__builtin_inff();
-          S.st = kView;  // level 0
-          S.pix = yl * (uint32_t)A.w + x;
-        }
-      }
+      if (st_kind(S.st) == kIdle && rank < take) GMLRT_CAMERA_RAY(cur_tile, (tile_base + rank) & 63u);
       tile_base += take;
       tile_left -= take;
       const unsigned long long idle_now = __ballot(st_kind(S.st) == kIdle);  // lanes that drew a padding slot are still idle
       n_primary += (uint32_t)__popcll(idle & ~idle_now);
       idle = idle_now;
     }
-    if (!__ballot(st_kind(S.st) != kIdle)) break;  // nothing in flight and nothing left to hand out
+    if (!__ballot(st_kind(S.st) != kIdle)) {
+      if (shared) continue;  // a shared tile of padding slots only: on to the next one
+      break;  // nothing in flight and nothing left to hand out
+    }
     DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
          dg.lanes += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
 
@@ -657,7 +699,30 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          const int dk = __ballot(st_kind(S.st) != kIdle && ((S.st >> 2) & 0x7FFu) != 0) ? 2 : __ballot(st_kind(S.st) == kShadow) ? 1 : 0;
          dg.kind = dk; dg.k_active[dk] += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
     // ---- one scene traversal for whatever ray each lane holds
-    Hit h = intersect_first(leaves, prog, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
+    Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
+    if constexpr (kShared) {
+      if (shared) {
+        // (a shadow ray's slice stops at its first candidate at or before the light; the nearest of the four is
+        // then at or before the light too, which is all the light test asks)
+        uint64_t* const xm = (uint64_t*)xq + kBlock;
+        if (wib != 0) {
+          xq[tid] = h.dist;
+          xm[tid] = (uint64_t)(h.meta | (h.any ? kHitAny : 0u)) | (h.redo ? 1ull << 32 : 0ull);
+          h.redo = false;
+        }
+        __syncthreads();
+        if (wib == 0) {
+          for (int w = 1; w < kBlock / kWave; w++) {
+            const double dw = xq[w * kWave + lane];
+            const uint64_t mw = xm[w * kWave + lane];
+            if (mw >> 32) h.redo = true;
+            if ((mw & kHitAny) && (!h.any || dw < h.dist || (dw == h.dist && ((uint32_t)mw & kLeafMask) < (h.meta & kLeafMask)))) {
+              h.any = true; h.dist = dw; h.meta = (uint32_t)mw & ~kHitAny;
+            }
+          }
+        }
+      }
+    }
     if (__ballot(h.redo)) {
       DIAG(dg.n_redo++;)
       // a primitive right under the root's unions gave a span shorter than 1e-10: only the
@@ -669,9 +734,32 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;
          dg.k_trav[dk]++; dg.k_leaf[dk] += dg.n_leaf - dk_leaf0;)
     uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
-    if (st_kind(S.st) != kIdle) {
+    if (st_kind(S.st) != kIdle && (!shared || wib == 0)) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
       S = after_traversal<kLdsCtx>(S, h.dist, hm, shade_args, &events);
+    }
+    if constexpr (kShared) {
+      if (shared) {
+        // wave 0's next rays to the other three (fields 2..9 of wave 1's lanes)
+        double* const xs = xq + 2 * kBlock + kWave + lane;
+        if (wib == 0) {
+          xs[0] = S.o.x; xs[kBlock] = S.o.y; xs[2 * kBlock] = S.o.z;
+          xs[3 * kBlock] = S.d.x; xs[4 * kBlock] = S.d.y; xs[5 * kBlock] = S.d.z;
+          ((uint64_t*)xs)[6 * kBlock] = (uint64_t)__float_as_uint(S.t_stop) | ((uint64_t)S.pix << 32);
+          ((uint64_t*)xs)[7 * kBlock] = (uint64_t)S.st;
+        }
+        __syncthreads();
+        if (wib != 0) {
+          S.o = {xs[0], xs[kBlock], xs[2 * kBlock]};
+          S.d = {xs[3 * kBlock], xs[4 * kBlock], xs[5 * kBlock]};
+          const uint64_t tp = ((uint64_t*)xs)[6 * kBlock];
+          S.t_stop = __uint_as_float((uint32_t)tp);
+          S.pix = (uint32_t)(tp >> 32);
+          S.st = (uint32_t)((uint64_t*)xs)[7 * kBlock];
+        }
+        // (the next round's candidates go to fields 0 and 1, its rays are written after the barrier that
+        // follows them: nothing here is overwritten while a wave may still read it)
+      }
     }
     n_shadow += (uint32_t)__popcll(__ballot((events & kStShadow) != 0));
     n_reflect += (uint32_t)__popcll(__ballot((events & kStReflect) != 0));
@@ -923,6 +1011,9 @@ void free_workspace(DeviceScene* s) {
   (void)hipFree(s->d_tile_order);
   (void)hipFree(s->d_tile_batch);
   (void)hipFree(s->d_tile_batch_img);
+  (void)hipFree(s->d_tile_order_rest);
+  (void)hipFree(s->d_tile_batch_rest);
+  (void)hipFree(s->d_tiles_shared);
   if (s->h_staging) (void)hipHostFree(s->h_staging);
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
@@ -1088,7 +1179,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   {
     uint32_t need_stack = 1;
     uint64_t need_events = 2;
-    std::vector<uint8_t> prog = derive_stream_program(blob, &need_stack, &need_events);
+    std::vector<uint8_t> prog = derive_stream_program(blob, &need_stack, &need_events, out->slice_off);
     out->max_stack = std::max(out->hdr.max_stack, need_stack);
     out->max_events = std::max<uint64_t>(out->hdr.max_events, need_events);
     if (out->max_events > 0xFFFFFFFFull) return "too large: event stack";
@@ -1136,7 +1227,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     hipDeviceProp_t q;
     HIP_TRY(hipGetDeviceProperties(&q, device));
     int b = 1;
-    if (lens_bytes <= 64 * 1024) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true>, kBlock, lens_bytes));
+    if (lens_bytes <= 64 * 1024) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true, false>, kBlock, lens_bytes));
     out->dev_cus = q.multiProcessorCount;
     out->dev_lds_block = q.sharedMemPerBlock;
     out->dev_lds_cu = q.maxSharedMemoryPerMultiProcessor;
@@ -1165,7 +1256,9 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.d_ev_dist = s->d_ev_dist; spare.d_ev_meta = s->d_ev_meta; spare.d_ctx = s->d_ctx;
   spare.d_counters = s->d_counters;
   spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc;
-  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img; spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
+  spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img;
+  spare.d_tile_order_rest = s->d_tile_order_rest; spare.d_tile_batch_rest = s->d_tile_batch_rest; spare.d_tiles_shared = s->d_tiles_shared;
+  spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
   {
@@ -1229,7 +1322,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (stats) {
     stats->rays_primary = stats->rays_shadow = stats->rays_reflect = stats->hits = 0;
     stats->kernel_ms = 0.0;
-    stats->reserved64 = 0;
+    stats->tiles_shared = 0;
   }
   if (rows == 0) return "";
 
@@ -1331,6 +1424,10 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     (void)hipFree(s->d_tile_batch);
     (void)hipFree(s->d_tile_batch_img);
     s->d_tile_batch = s->d_tile_batch_img = nullptr;
+    (void)hipFree(s->d_tile_order_rest);
+    (void)hipFree(s->d_tile_batch_rest);
+    (void)hipFree(s->d_tiles_shared);
+    s->d_tile_order_rest = s->d_tile_batch_rest = s->d_tiles_shared = nullptr;
     s->tiles_alloc = 0;
     s->order_valid = false;
 
@@ -1338,6 +1435,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     HIP_TRY(hipMalloc(&s->d_tile_order, n_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch, (n_tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->d_tile_batch_img, (n_tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_tile_order_rest, n_tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_tile_batch_rest, (n_tiles + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->d_tiles_shared, n_tiles * sizeof(uint32_t)));
     s->tiles_alloc = n_tiles;
   }
   gmlrt_params key = p;
@@ -1351,13 +1451,16 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   static const bool no_order_env = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
   // (a call that must not allocate neither learns a hand-out order nor uses one: the tables are allocations)
   const bool no_order = no_order_env || no_alloc;
-  const int way = !s->order_valid || no_order ? 0 : s->order_state == 1 ? 1 : s->order_state == 2 ? 2 : s->order_state == 3 ? s->order_way : 0;
-  const bool ordered = way == 1;
-  A.tile_order = ordered ? (const uint32_t*)s->d_tile_order : nullptr;
-  A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img : nullptr;
+  const int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 3 ? s->order_state : s->order_state == 4 ? s->order_way : 0;
+  A.tile_order = way == 1 ? (const uint32_t*)s->d_tile_order : way == 3 ? (const uint32_t*)s->d_tile_order_rest : nullptr;
+  A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img
+                  : way == 3 ? (const uint32_t*)s->d_tile_batch_rest : nullptr;
   A.n_tiles = (uint32_t)n_tiles;
   A.stride = 1;
-  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : way == 3 ? s->n_batches_rest : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  A.tiles_shared = way == 3 ? (const uint32_t*)s->d_tiles_shared : nullptr;
+  A.n_tiles_shared = way == 3 ? s->n_tiles_shared : 0u;
+  for (uint32_t k = 0; k < kProgSlices; k++) A.slice_off[k] = s->slice_off[k];
   static const bool no_stride = std::getenv("GMLRT_IMAGE_ORDER") != nullptr;  // tuning runs
   if (way == 0 && !no_stride && H.n_leaves > 16) {
     // No tile costs known (a handle that renders once, or the first launch of one that will learn them, or a
@@ -1371,6 +1474,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     if (st < n_tiles) A.stride = (uint32_t)st;
   }
   A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
+  static const bool verbose_shared = std::getenv("GMLRT_VERBOSE") != nullptr;
+  if (verbose_shared && way == 3 && s->order_state == 3) A.tile_cost = (uint32_t*)s->d_tile_cost;  // (what sharing did to the dear tiles, for the log)
 #ifdef GMLRT_DIAG
   unsigned long long* d_tile_dbg = nullptr;
   HIP_TRY(hipMalloc(&d_tile_dbg, n_tiles * 4 * sizeof(unsigned long long)));
@@ -1417,11 +1522,14 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   std::memcpy(s->h_staging, &SA, sizeof(SA));
   HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, kOffBlockCounts - kOffShadeArgs, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
-  if (A.lds_ctx)
-    hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+  if (A.lds_ctx && A.n_tiles_shared)
+    hipLaunchKernelGGL((render_kernel<true, true>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
+  else if (A.lds_ctx)
+    hipLaunchKernelGGL((render_kernel<true, false>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   else
-    hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+    hipLaunchKernelGGL((render_kernel<false, false>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
@@ -1437,18 +1545,32 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
   if (no_alloc) {
     // nothing to learn and nothing to record
-  } else if ((s->order_state == 1 || s->order_state == 2) && way == s->order_state) {
+  } else if (s->order_state >= 1 && s->order_state <= 3 && way == s->order_state) {
     // a trial: the learnt order trades cache locality between neighbouring waves for a shorter tail (scenes
-    // with evenly priced tiles lose); the batch table over the image order only saves atomics
+    // with evenly priced tiles lose); the batch table over the image order only saves atomics; sharing the
+    // dearest tiles among the waves of a block costs total work and pays when those tiles set the launch's length
     s->order_ms[way] = ms;
-    if (++s->order_state == 3) {
+    if (verbose_shared && way == 3 && !s->learnt_cost.empty()) {
+      std::vector<uint32_t> now(n_tiles), list(s->n_tiles_shared);
+      HIP_TRY(hipMemcpy(now.data(), s->d_tile_cost, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(list.data(), s->d_tiles_shared, list.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      double before = 0, after = 0;
+      for (uint32_t t : list) { before += s->learnt_cost[t]; after += now[t]; }
+      std::fprintf(stderr, "[gmlrt] shared tiles: %.1f us each alone, %.1f us each shared; dearest %.1f -> %.1f, median %.1f -> %.1f\n",
+                   before / list.size() / 100.0, after / list.size() / 100.0, s->learnt_cost[list[0]] / 100.0, now[list[0]] / 100.0,
+                   s->learnt_cost[list[list.size() / 2]] / 100.0, now[list[list.size() / 2]] / 100.0);
+    }
+    s->order_state++;
+    if (s->order_state == 3 && s->n_tiles_shared == 0) s->order_state = 4;  // no tile dear enough: nothing to try
+    if (s->order_state == 4) {
       s->order_way = 0;
       float best = 0.98f * s->order_ms[0];
-      for (int k = 1; k <= 2; k++)
+      for (int k = 1; k <= (s->n_tiles_shared ? 3 : 2); k++)
         if (s->order_ms[k] < best) { best = s->order_ms[k]; s->order_way = k; }
       if (std::getenv("GMLRT_VERBOSE"))
-        std::fprintf(stderr, "[gmlrt] tile hand-out: no costs known %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms -> way %d\n",
-                     s->order_ms[0], s->order_ms[1], s->order_ms[2], s->order_way);
+        std::fprintf(stderr, "[gmlrt] tile hand-out: no costs known %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms, "
+                     "learnt order with %u shared tiles %.3f ms -> way %d\n",
+                     s->order_ms[0], s->order_ms[1], s->order_ms[2], s->n_tiles_shared, s->order_ms[3], s->order_way);
     }
   } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
     // first launch with this geometry: turn its per-tile costs into the order of the next ones
@@ -1485,6 +1607,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       }
 #endif
     }
+    if (verbose_shared) s->learnt_cost = cost;
     tiles_by_cost(cost, n_classes, &order);
     HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
@@ -1496,8 +1619,49 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
       batches_by_cost(cost, nullptr, waves, (double)ms, &start);
       s->n_batches_img = (uint32_t)start.size() - 1;
       HIP_TRY(hipMemcpy(s->d_tile_batch_img, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      // Way 3: a tile that alone takes more than a share of what a wave has to do in the whole launch is rendered
+      // by a block's four waves together, dearest first, before anything else; the rest keeps the learnt order.
+      s->n_tiles_shared = 0;
+      s->n_batches_rest = 0;
+      // The threshold: sharing makes the dearest tile about 2.4 times shorter (measured; the per-ray code stays
+      // serial and the slices never balance) at 4 waves' expense, so nothing cheaper than the dearest tile's
+      // shared time is worth sharing, and nothing that a wave could do alone within its fair part of the launch.
+      // (tuning runs and tests: a fixed fraction of a wave's fair part instead; 0 switches sharing off.  Read at every learning launch.)
+      const double share = [] { const char* e = std::getenv("GMLRT_SHARED_TILE_SHARE"); return e ? std::atof(e) : -1.0; }();
+      if (A.lds_ctx && s->slice_off[0] != 0 && share != 0.0) {
+        unsigned long long total = 0;
+        uint32_t top = 0;
+        for (uint32_t c : cost) { total += c; top = std::max(top, c); }
+        const double per_wave = (double)total / (double)waves;
+        const double threshold = share > 0.0 ? share * per_wave : std::max((double)top / 2.4, per_wave);
+        std::vector<uint32_t> dear, rest_cost;
+        std::vector<uint32_t> keep;  // tiles that stay in the ordinary hand-out, in image order
+        for (size_t i = 0; i < n_tiles; i++) {
+          if ((double)cost[i] > threshold) dear.push_back((uint32_t)i);
+          else keep.push_back((uint32_t)i);
+        }
+        // at most a few per block: beyond that the tiles are not what sets the length of the launch
+        std::sort(dear.begin(), dear.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
+        const size_t cap = 4 * (size_t)grid;
+        while (dear.size() > cap) { keep.push_back(dear.back()); dear.pop_back(); }
+        if (!dear.empty() && !keep.empty()) {
+          std::sort(keep.begin(), keep.end());
+          rest_cost.resize(keep.size());
+          for (size_t i = 0; i < keep.size(); i++) rest_cost[i] = cost[keep[i]];
+          std::vector<uint32_t> rest_order;
+          tiles_by_cost(rest_cost, n_classes, &rest_order);
+          batches_by_cost(rest_cost, &rest_order, waves, (double)ms, &start);
+          for (uint32_t& t : rest_order) t = keep[t];
+          s->n_batches_rest = (uint32_t)start.size() - 1;
+          s->n_tiles_shared = (uint32_t)dear.size();
+          HIP_TRY(hipMemcpy(s->d_tile_order_rest, rest_order.data(), rest_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+          HIP_TRY(hipMemcpy(s->d_tile_batch_rest, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+          HIP_TRY(hipMemcpy(s->d_tiles_shared, dear.data(), dear.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+      }
       if (std::getenv("GMLRT_VERBOSE"))
-        std::fprintf(stderr, "[gmlrt] %zu tiles in %u batches (learnt order), %u batches (image order)\n", n_tiles, s->n_batches, s->n_batches_img);
+        std::fprintf(stderr, "[gmlrt] %zu tiles in %u batches (learnt order), %u batches (image order); %u tiles dear enough to share\n",
+                     n_tiles, s->n_batches, s->n_batches_img, s->n_tiles_shared);
     }
     s->order_key = key;
     s->order_valid = true;
@@ -1602,7 +1766,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->rays_reflect = counts[2];
     stats->hits = counts[3];
     stats->kernel_ms = (double)ms;
-    stats->reserved64 = 0;
+    stats->tiles_shared = A.n_tiles_shared;
     stats->surface_errors = *(const uint32_t*)((const uint8_t*)s->h_staging + 1024 - 8) ? 1u : 0u;
   }
   return "";

@@ -84,7 +84,7 @@ struct Stream {
 };
 }  // namespace
 
-std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events) {
+std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stack, uint64_t* need_events, uint32_t* slice_off) {
   gmlrt_blob_header H;
   std::memcpy(&H, blob, sizeof(H));
   const uint8_t* base = (const uint8_t*)blob;
@@ -345,7 +345,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   // (half-spaces) are visited by every ray, and so is, in effect, a child that spans most of the
   // scene (a floor slab): both stay outside the tree and come first, so that a hit on them can
   // already cull what lies behind it.
-  auto emit_regrouped = [&]() {
+  auto emit_regrouped = [&](const std::vector<int>& its) {
   std::vector<int> grouped;
   {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -354,13 +354,13 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
       if (e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0) return 0.0;
       return 2.0 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
     };
-    for (int ni : items) {
+    for (int ni : items) {  // (all of them, also for a slice: what counts as "spans the scene" does not depend on the slice)
       if (tree[(size_t)ni].bound < 0) continue;
       const gmlrt_bound& b = bounds[tree[(size_t)ni].bound];
       for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
     }
     const double all_area = box_area(lo, hi);
-    for (int ni : items) {
+    for (int ni : its) {
       const int bi = tree[(size_t)ni].bound;
       if (bi < 0 || !(box_area(bounds[bi].lo, bounds[bi].hi) <= 0.25 * all_area)) emit_item(ni);
       else grouped.push_back(ni);
@@ -475,7 +475,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   given.swap(S.bytes);
   cost = 0.0;
   open_p.clear();
-  emit_regrouped();
+  emit_regrouped(items);
   bool regroup = cost < cost_given;
   if (const char* e = std::getenv("GMLRT_REGROUP")) regroup = *e == '1';  // tuning runs
   if (std::getenv("GMLRT_VERBOSE"))
@@ -483,6 +483,89 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
                  items.size(), cost_given, cost, regroup ? "regrouped" : "as given");
   if (!regroup) S.bytes.swap(given);
   put_small(kRecEnd, 0);
+  // ---- slices: the same frontier dealt out to kProgSlices programs of their own, for the four waves of a block
+  // that trace the SAME rays together (each wave walks one slice, the nearest candidate of the four is the
+  // nearest of the whole frontier: the rule that picks it, distance then leaf index, does not care in which
+  // order or by whom the candidates were found).  Children are dealt round-robin in the order of the
+  // regrouped arrangement, neighbours to different slices, so that the pieces a ray passes are spread over
+  // the waves; every slice gets its own hierarchy of boxes.  Offsets in a slice are offsets into the whole
+  // buffer, like everywhere else.
+  for (uint32_t k = 0; k < kProgSlices; k++) slice_off[k] = 0;
+  if (items.size() >= 2 * (size_t)kProgSlices && tree[(size_t)st[0]].nl >= 32) {
+    // spatial order: a walk through the emitted frontier, children in the order their first leaf appears
+    std::vector<int> spatial;
+    {
+      std::map<uint32_t, int> by_first_leaf;
+      for (int ni : items) {
+        int q = ni;
+        while ((tree[(size_t)q].word >> 30) == 1) q = tree[(size_t)q].a;
+        by_first_leaf[tree[(size_t)q].word & 0x3FFFFFFFu] = ni;
+      }
+      std::vector<char> seen(tree.size(), 0);
+      for (size_t at = 0; at + 16 <= S.bytes.size();) {
+        uint32_t kind, leaf;
+        std::memcpy(&kind, S.bytes.data() + at, 4);
+        std::memcpy(&leaf, S.bytes.data() + at + 4, 4);
+        const uint32_t kk = kind & 0xFu;
+        if (kk == kRecEnd) break;
+        if (kk == kRecLeaf) {
+          auto it = by_first_leaf.find(leaf);
+          if (it != by_first_leaf.end() && !seen[(size_t)it->second]) { seen[(size_t)it->second] = 1; spatial.push_back(it->second); }
+        }
+        at += kk == kRecLeaf ? sizeof(ProgLeaf) : (kk == kRecBound || kk == kRecBox) ? sizeof(ProgBound) : sizeof(ProgSmall);
+      }
+      for (int ni : items) if (!seen[(size_t)ni]) spatial.push_back(ni);  // (a lazily swapped first operand hides a child's first leaf)
+    }
+    // Which slice a child goes to: the one where it adds least to  sum over the slice's children of
+    // leaves(child) * leaves(other) / (distance^2 + size^2)  -- children of one slice end up far from each other
+    // in every direction (a ray meets neighbours, not the whole board, and the waves should share what it
+    // meets), and the slices hold about the same number of leaves.  Children without a finite box are met by
+    // every ray: they are dealt round-robin.
+    std::vector<std::vector<int>> deal(kProgSlices);
+    {
+      std::vector<double> load(kProgSlices, 0.0);
+      uint32_t rr = 0;
+      auto ctr = [&](int ni, double* c, double* size2) {
+        const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
+        *size2 = 0.0;
+        for (int k = 0; k < 3; k++) { c[k] = 0.5 * (g.lo[k] + g.hi[k]); const double e = g.hi[k] - g.lo[k]; *size2 += e * e; }
+        return std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(*size2);
+      };
+      for (int ni : spatial) {
+        double c[3], s2;
+        // (quadratic in the number of children: a frontier of thousands is dealt round-robin in its spatial order)
+        if (spatial.size() > 2048 || tree[(size_t)ni].bound < 0 || !ctr(ni, c, &s2)) { deal[rr++ % kProgSlices].push_back(ni); continue; }
+        uint32_t best = 0;
+        double best_v = INFINITY;
+        for (uint32_t k = 0; k < kProgSlices; k++) {
+          double v = 1e-9 * load[k];
+          for (int nj : deal[k]) {
+            double cj[3], sj;
+            if (tree[(size_t)nj].bound < 0 || !ctr(nj, cj, &sj)) continue;
+            const double d2 = (c[0] - cj[0]) * (c[0] - cj[0]) + (c[1] - cj[1]) * (c[1] - cj[1]) + (c[2] - cj[2]) * (c[2] - cj[2]);
+            v += (double)tree[(size_t)nj].nl / (d2 + 0.25 * (s2 + sj) + 1e-300);
+          }
+          if (v < best_v) { best_v = v; best = k; }
+        }
+        deal[best].push_back(ni);
+        load[best] += (double)tree[(size_t)ni].nl;
+      }
+    }
+    for (uint32_t k = 0; k < kProgSlices; k++) {
+      std::vector<int>& mine = deal[k];
+      std::sort(mine.begin(), mine.end());  // program order within the slice, as the whole frontier has it
+      while (S.bytes.size() % 64) S.bytes.push_back(0);
+      slice_off[k] = (uint32_t)S.bytes.size();
+      open_p.clear();
+      emit_regrouped(mine);
+      put_small(kRecEnd, 0);
+      if (std::getenv("GMLRT_VERBOSE")) {
+        uint32_t nl = 0;
+        for (int ni : mine) nl += tree[(size_t)ni].nl;
+        std::fprintf(stderr, "[gmlrt] slice %u: %zu children, %u leaves, at byte %u\n", k, mine.size(), nl, slice_off[k]);
+      }
+    }
+  }
   if (std::getenv("GMLRT_VERBOSE")) {
     size_t n_kind[8] = {0};
     for (size_t at = 0; at + 16 <= S.bytes.size();) {

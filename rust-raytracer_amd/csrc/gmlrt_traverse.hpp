@@ -25,7 +25,7 @@
 constexpr uint32_t kFlActive = 1u, kFlRedo = 2u;
 
 __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restrict__ leaves, const uint8_t* __restrict__ prog,
-                                      uint32_t n_leaves, bool active_in, V3 o, V3 d, const double t_stop,
+                                      const uint32_t pc_start, uint32_t n_leaves, bool active_in, V3 o, V3 d, const double t_stop,
                                       double* __restrict__ evD, uint32_t* __restrict__ evM,
                                       uint16_t* __restrict__ lens, Diag& dg) {
   Hit h = {false, 0.0, 0u, false};
@@ -47,7 +47,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
   uint32_t sp = 0;       // events on this lane's stack
   uint32_t level = 0;    // operand stack depth (wave-uniform)
   const int tid = threadIdx.x;
-  uint32_t pc = 0;       // byte offset of the current record (wave-uniform)
+  uint32_t pc = pc_start;  // byte offset of the current record (wave-uniform): 0, or where a slice of the frontier starts
   // For the box tests, in single precision: t = p * inv - o * inv for a slab plane p, one fused operation per
   // plane.  Against the exact value the computed t is off by at most
   //     E = 2^-21 * (|p| + |o|) * |inv|      (p rounded outwards to f32: 2^-23 relative; inv and o * inv rounded

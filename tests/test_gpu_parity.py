@@ -100,6 +100,50 @@ def test_every_way_of_handing_out_tiles_gives_the_same_image(gmlrt, name, size, 
     assert st_ref.rays_primary == size[0] * size[1]
 
 
+@pytest.mark.parametrize("name,size,depth,nparts,part,share", [
+    ("chess", (3840, 2160), 5, 8, 3, None),      # the tiles the library itself finds dear enough
+    ("chess", (3840, 2160), 5, 4, 0, None),
+    ("chess", (3840, 2160), 5, 1, 0, "0.3"),     # forced: hundreds of tiles, several per block
+    ("chess", (1921, 1081), 5, 2, 1, "0.02"),    # forced: nearly every tile, ragged ones included
+    ("fractal", (3840, 2160), 3, 1, 0, "0.2"),   # a frontier of thousands of children, dealt round-robin
+    ("cone-fractal", (1920, 1080), 4, 1, 0, "0.1"),
+])
+def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, name, size, depth, nparts, part, share):
+    # Way 3 of handing out tiles: the dearest ones are rendered by four waves together, each walking a quarter of
+    # the scene's frontier for the same 64 rays (launch 4 of a handle tries it, later launches may keep it).  Same
+    # bytes and same ray counts as the launch that knew no costs, and as the rows of the one-shot render.
+    import torch
+    call = gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].with_overrides(size[0], size[1], depth)
+    full, _, _ = gmlrt.render(call)
+    h, w = size[1], size[0]
+    rows = gmlrt.part_row_index(h, 8, part, nparts)
+    p = gmlrt.Params()
+    ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
+    p.tile_rows, p.part, p.nparts = 8, part, nparts
+    old = os.environ.get("GMLRT_SHARED_TILE_SHARE")
+    if share is not None:
+        os.environ["GMLRT_SHARED_TILE_SHARE"] = share
+    try:
+        scene = gmlrt.DeviceScene(call.blob, 0)
+        buf = torch.empty((len(rows), w, 3), dtype=torch.uint8, device="cuda:0")
+        first, shared_seen = None, False
+        for launch in range(6):
+            buf.fill_(0x5A)
+            st = scene.render_into(p, buf.data_ptr())
+            assert (buf.cpu().numpy() == full[rows]).all(), (name, launch)
+            counts = (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits)
+            first = first or counts
+            assert counts == first, (name, launch)
+            shared_seen = shared_seen or st.tiles_shared > 0
+        scene.close()
+        assert shared_seen, "no launch of the handle shared a tile: the case tests nothing"
+    finally:
+        if share is None or old is None:
+            os.environ.pop("GMLRT_SHARED_TILE_SHARE", None)
+        if old is not None:
+            os.environ["GMLRT_SHARED_TILE_SHARE"] = old
+
+
 def test_repeated_render_is_deterministic(gmlrt):
     prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
     a, _, sa = gmlrt.render(prog.calls[0])
