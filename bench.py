@@ -182,24 +182,60 @@ def main():
             gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
     gather_s = [0.0]
+    # With the host framebuffer, a step's rows travel to the host while the next step renders: two device buffers
+    # in turn, and one thread per rank that does the copying (the library call blocks and runs on a stream of its
+    # own).  Every step still renders the whole partition and delivers all of its rows; the clock stops only after
+    # the last copy has landed.
+    outs = [out, torch.zeros_like(out)] if shared is not None else [out]
+    copy_jobs = None
+    if shared is not None:
+        import queue, threading
+        copy_jobs = queue.Queue()
+        copy_err = []
+
+        def copier():
+            while True:
+                buf = copy_jobs.get()
+                try:
+                    if buf is None:
+                        return
+                    t = time.perf_counter()
+                    shared.put_rows_from_device(local_rank, buf.data_ptr())
+                    gather_s[0] += time.perf_counter() - t
+                except Exception as e:  # noqa: BLE001 (reported by the main thread)
+                    copy_err.append(e)
+                finally:
+                    copy_jobs.task_done()
+        threading.Thread(target=copier, daemon=True).start()
+    n_step = [0]
 
     def step():
-        st = scene.render_into(p, out.data_ptr(), None, stream)  # returns when the kernel is done
-        if world > 1:
+        buf = outs[n_step[0] % len(outs)]
+        n_step[0] += 1
+        st = scene.render_into(p, buf.data_ptr(), None, stream)  # returns when the kernel is done
+        if copy_jobs is not None:
+            while copy_jobs.unfinished_tasks >= len(outs):  # the buffer about to be rendered into next must have left
+                time.sleep(0)
+            copy_jobs.put(buf)
+        elif world > 1:
             t = time.perf_counter()
-            if shared is not None:
-                shared.put_rows_from_device(local_rank, out.data_ptr())
-            else:
-                rowtiles.gather_to_rank0(out, gathered)
-                torch.cuda.synchronize()
+            rowtiles.gather_to_rank0(buf, gathered)
+            torch.cuda.synchronize()
             gather_s[0] += time.perf_counter() - t
         return st
 
+    def drain():
+        if copy_jobs is not None:
+            copy_jobs.join()
+            if copy_err:
+                raise copy_err[0]
+
     # Scene preparation, like the upload above: the library times the pixel tiles in the first launch with a
-    # given geometry and tries two other ways of handing them out in the second and third (gmlrt_kernels.hip).
-    learn_ms = [scene.render_into(p, out.data_ptr(), None, stream).kernel_ms for _ in range(3)]
+    # given geometry and tries up to three other ways of handing them out in the launches that follow (gmlrt_kernels.hip).
+    learn_ms = [scene.render_into(p, out.data_ptr(), None, stream).kernel_ms for _ in range(4)]
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -211,10 +247,12 @@ def main():
         rays += st.rays
         hits += st.hits
         kernel_ms += st.kernel_ms
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    out = outs[(n_step[0] - 1) % len(outs)] if n_step[0] else out
 
     # whole-job figures: max time over ranks, rays summed over ranks
     red_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -267,7 +305,7 @@ def main():
             "config": {"workload": workload,
                        "leaves": n_leaves, "flops_per_ray": flops_per_ray,
                        "rays_per_frame": int(rays_per_step), "parallelism": "row-tiles x%d (tile %d rows)" % (world, TILE_ROWS),
-                       "gather": ("host framebuffer shared by the ranks, every rank copies its own rows" if shared is not None else
+                       "gather": ("host framebuffer shared by the ranks, every rank copies its own rows while its next step renders" if shared is not None else
                                   "dist.gather to rank 0" if world > 1 else "none")},
             "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
             "gather_ms_per_step": round(gather_s_max * 1e3, 4) if world > 1 else None,

@@ -155,6 +155,13 @@ static_assert(sizeof(ShadeArgs) <= kOffSurfError - kOffShadeArgs, "ShadeArgs out
 struct Diag { unsigned long long t_refill, t_trav, t_after, n_trav, n_bound, n_skip, n_leaf, n_merge, n_take, lanes, n_redo,
               b_lanes, l_lanes, l_hits, k_trav[3], k_leaf[3], l_nohit, k_entered[3], k_blanes[3], k_active[3]; int kind;
               unsigned long long* leaf_dbg; };
+// -DGMLRT_DIAG_SHARED: where the four waves of a block spend their time on shared tiles (own slice, waiting for
+// the others' candidates, per-ray code, waiting for the next rays), per wave of the block.  Diagnostic builds only.
+#ifdef GMLRT_DIAG_SHARED
+#define DIAGS(...) __VA_ARGS__
+#else
+#define DIAGS(...)
+#endif
 #ifdef GMLRT_DIAG
 #define DIAG(...) __VA_ARGS__
 #else
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   uint32_t shared_next = blockIdx.x;
   bool shared = false;
   uint32_t pc0 = 0, shared_tile = 0;
+  DIAGS(unsigned long long ds_phase[4] = {0, 0, 0, 0}, ds_t = 0;)
   [[maybe_unused]] double* const xq = (double*)((uint8_t*)lens + A.vm_lds_off);
 
   for (;;) {
@@ -699,18 +707,21 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          const int dk = __ballot(st_kind(S.st) != kIdle && ((S.st >> 2) & 0x7FFu) != 0) ? 2 : __ballot(st_kind(S.st) == kShadow) ? 1 : 0;
          dg.kind = dk; dg.k_active[dk] += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
     // ---- one scene traversal for whatever ray each lane holds
+    DIAGS(ds_t = __builtin_readcyclecounter();)
     Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if constexpr (kShared) {
       if (shared) {
         // (a shadow ray's slice stops at its first candidate at or before the light; the nearest of the four is
         // then at or before the light too, which is all the light test asks)
         uint64_t* const xm = (uint64_t*)xq + kBlock;
+        DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[0] += n_ - ds_t; ds_t = n_; })
         if (wib != 0) {
           xq[tid] = h.dist;
           xm[tid] = (uint64_t)(h.meta | (h.any ? kHitAny : 0u)) | (h.redo ? 1ull << 32 : 0ull);
           h.redo = false;
         }
         __syncthreads();
+        DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[1] += n_ - ds_t; ds_t = n_; })
         if (wib == 0) {
           for (int w = 1; w < kBlock / kWave; w++) {
             const double dw = xq[w * kWave + lane];
@@ -742,6 +753,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       if (shared) {
         // wave 0's next rays to the other three (fields 2..9 of wave 1's lanes)
         double* const xs = xq + 2 * kBlock + kWave + lane;
+        DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[2] += n_ - ds_t; ds_t = n_; })
         if (wib == 0) {
           xs[0] = S.o.x; xs[kBlock] = S.o.y; xs[2 * kBlock] = S.o.z;
           xs[3 * kBlock] = S.d.x; xs[4 * kBlock] = S.d.y; xs[5 * kBlock] = S.d.z;
@@ -749,6 +761,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           ((uint64_t*)xs)[7 * kBlock] = (uint64_t)S.st;
         }
         __syncthreads();
+        DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[3] += n_ - ds_t; ds_t = n_; })
         if (wib != 0) {
           S.o = {xs[0], xs[kBlock], xs[2 * kBlock]};
           S.d = {xs[3 * kBlock], xs[4 * kBlock], xs[5 * kBlock]};
@@ -782,6 +795,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       A.block_counts[(size_t)blockIdx.x * 4 + tid] = sum;
     }
   }
+  DIAGS(if (lane == 0) for (int q = 0; q < 4; q++) atomicAdd(&A.diag[wib * 4 + q], ds_phase[q]);)
   if (lane == 0) {
     DIAG(shade_args->diag_waves[wave * kDiagWaveSlots + 8] = w_start; shade_args->diag_waves[wave * kDiagWaveSlots + 9] = wall_clock64();
          shade_args->diag_waves[wave * kDiagWaveSlots + 10] = w_tiles;)
@@ -1668,6 +1682,15 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     s->order_state = 1;
     s->order_ms[0] = ms;
   }
+#ifdef GMLRT_DIAG_SHARED
+  if (A.n_tiles_shared) {
+    unsigned long long v[16];
+    HIP_TRY(hipMemcpy(v, (uint8_t*)d_counters + kOffDiag, sizeof(v), hipMemcpyDeviceToHost));
+    for (int w = 0; w < 4; w++)
+      std::fprintf(stderr, "[gmlrt shared] wave %d of a block, Mcycles over %u tiles: own slice %.1f, wait for candidates %.1f, per-ray code %.1f, wait for rays %.1f\n",
+                   w, A.n_tiles_shared, v[w * 4] / 1e6, v[w * 4 + 1] / 1e6, v[w * 4 + 2] / 1e6, v[w * 4 + 3] / 1e6);
+  }
+#endif
 #ifdef GMLRT_DIAG
   {
     unsigned long long dgv[16];
