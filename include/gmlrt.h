@@ -177,7 +177,9 @@ typedef struct gmlrt_stats {
   uint64_t rays_reflect; /* one per hit with ks > 0 && depth > 0 (raytracer.rs:100)  */
   double kernel_ms;      /* device time of the render kernel (HIP events; max over GPUs) */
   double total_ms;       /* host wall time of the call                               */
-  uint64_t tiles_shared; /* 8x8-pixel tiles of this launch that four waves rendered together (0 on most launches) */
+  uint32_t tiles_shared; /* 8x8-pixel tiles of this launch that four waves rendered together (0 on most launches) */
+  uint32_t handout_way;  /* how the launch dealt its tiles (gmlrt_render_device's note): 0 no costs known, 1 learnt order,
+                            2 image order in cost-balanced batches, 3 learnt order with shared tiles, 4 rays regrouped */
   uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
   uint32_t surface_errors; /* non-zero: some shaded hit raised GMLRT_SOP_TRAP (the call returns GMLRT_ERR_SURFACE) */

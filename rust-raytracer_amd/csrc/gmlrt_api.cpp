@@ -128,6 +128,7 @@ int surface_failure() {
 void add_stats(gmlrt_stats* total, const gmlrt_stats& st, bool sum_kernel_ms) {
   total->surface_errors |= st.surface_errors;
   total->tiles_shared += st.tiles_shared;
+  if (st.handout_way > total->handout_way) total->handout_way = st.handout_way;
   total->rays_primary += st.rays_primary;
   total->rays_shadow += st.rays_shadow;
   total->rays_reflect += st.rays_reflect;

@@ -95,17 +95,20 @@ struct DeviceScene {
   // Four ways of handing out the tiles: 0 image order, fixed small batches; 1 the learnt order with its batch
   // table; 2 image order with a batch table of its own; 3 the learnt order with the dearest tiles taken out and
   // rendered first, each by the four waves of a block together (only when the launch has tiles dear enough to set
-  // its length).  order_state counts the launches with this geometry: 0 nothing learnt (runs way 0 and times its
-  // tiles), 1, 2, 3: that way on trial, 4: decided (order_way).
+  // its length); 4 the learnt order, run by the kernel that sorts the rays of a block into its waves before every
+  // traversal.  order_state counts the launches with this geometry: 0 nothing learnt (runs way 0 and times its
+  // tiles), 1 .. 4: that way on trial, 5: decided (order_way).
   int order_state = 0;
   int order_way = 0;            // the fastest of them (a trial has to beat way 0 by 2 %)
-  float order_ms[4] = {0.f, 0.f, 0.f, 0.f};  // kernel time of the launch that ran each way
+  float order_ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // kernel time of the launch that ran each way (0: not tried)
   void* d_tile_batch_img = nullptr;      // way 2's batch table
   uint32_t n_batches_img = 0;
   void* d_tile_order_rest = nullptr;     // way 3: order and batch table of the tiles that are not shared, and the shared ones
   void* d_tile_batch_rest = nullptr;
   void* d_tiles_shared = nullptr;
   uint32_t n_batches_rest = 0, n_tiles_shared = 0;
+  void* d_xchg = nullptr;                // way 4: ray states on their way between lanes, 16 KB a block
+  uint64_t xchg_blocks = 0;
   std::vector<uint32_t> learnt_cost;     // verbose runs only: the costs the tables were made from
   gmlrt_params order_key{};     // the launch parameters the order belongs to (ambient zeroed)
   void* h_staging = nullptr;    // page-locked host memory for the launch record and the per-block ray counts

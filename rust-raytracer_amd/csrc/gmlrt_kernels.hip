@@ -115,6 +115,8 @@ struct KArgs {
   // program slice of each wave of the block starts.
   const uint32_t* tiles_shared;
   uint32_t n_tiles_shared;
+  uint32_t regroup_mode;           // bits 1..0: what the rays are sorted by (tuning); bit 2: new tiles only for an idle block
+  uint64_t* xchg;                  // the regrouping kernel: 256 x 8 words per block, the ray states on their way to their new lanes
   uint32_t slice_off[kProgSlices];
   unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
   unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
@@ -536,13 +538,15 @@ __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 #endif
 // kLdsCtx: the block's LDS has room for the hot fields of the shading context (see gmlrt_shade.hpp);
 // a kernel per case, so that the loop below holds a single call site of after_traversal.
-// kShared: the launch has tiles that the waves of a block render together (needs the LDS context region); a kernel of its own, so that
-// the ordinary one carries none of that.
-template <bool kLdsCtx, bool kShared>
+// kMode: 0 the ordinary kernel; 1 the launch has tiles that the waves of a block render together; 2 the rays of a block are
+// regrouped before every traversal (both need the LDS context region).  Kernels of their own, so that the ordinary one
+// carries none of that.
+template <bool kLdsCtx, int kMode>
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
     const uint8_t* __restrict__ prog, const ShadeArgs* __restrict__ shade_args, const KArgs A) {
+  constexpr bool kShared = kMode == 1, kRegroup = kMode == 2;
   extern __shared__ __align__(16) uint16_t lens[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   S.d = {0, 0, 1};
   S.t_stop = -__builtin_inff();
   S.pix = 0;
-  S.st = kIdle;
+  S.st = kIdle | (kRegroup ? (uint32_t)tid << 24 : 0u);  // (regrouping: the context slot the ray owns travels in bits 31..24)
   // ray counts of the whole wave, kept as scalars (a per-lane count would be one more vector register to
   // save around every call of the per-ray code)
   uint32_t n_primary = 0, n_shadow = 0, n_reflect = 0, n_hits = 0;
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       S.o = {0.0, 0.0, -1.0};                                                                                      \
       S.d = vnormalize(dir);                                                                                       \
       S.t_stop = -__builtin_inff();                                                                                \
-      S.st = kView; /* level 0 */                                                                                  \
+      S.st = kView | (kRegroup ? S.st & 0xFF000000u : 0u); /* level 0 */                                           \
       S.pix = yl * (uint32_t)A.w + x;                                                                              \
     }                                                                                                              \
   } while (0)
@@ -618,7 +622,59 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   DIAGS(unsigned long long ds_phase[4] = {0, 0, 0, 0}, ds_t = 0;)
   [[maybe_unused]] double* const xq = (double*)((uint8_t*)lens + A.vm_lds_off);
 
+  [[maybe_unused]] uint32_t n_idle = 0;  // regrouping: idle lanes of the whole block
   for (;;) {
+    if constexpr (kRegroup) {
+      // ---- the block's 256 rays, sorted into its four waves by what they are: camera rays, their shadow rays,
+      // rays after a bounce by the quadrant of their direction, shadow rays after a bounce; idle lanes last, so
+      // that a wave either is full of rays of a kind or has nothing to do (and takes a new tile when all its
+      // lanes are idle).  A counting sort that keeps the order within a kind: rays of one tile stay neighbours.
+      // A ray takes its state along (through device memory: 64 bytes a ray) and the number of its context slot.
+      constexpr uint32_t kKeys = 8;
+      const uint32_t knd = (uint32_t)st_kind(S.st), lvl = (S.st >> 2) & 0x7FFu;
+      const uint32_t key = knd == kIdle ? kKeys - 1 : (A.regroup_mode & 3u) == 1u ? 0u : lvl == 0 ? (knd == kView ? 0u : 1u)
+                           : (A.regroup_mode & 3u) == 2u ? (knd == kView ? 2u : 3u)
+                           : knd == kShadow ? 6u : 2u + (S.d.x < 0.0 ? 1u : 0u) + (S.d.z < 0.0 ? 2u : 0u);
+      // counts of this wave, in the operand-stack slots of its own lanes (dead between its traversals)
+      uint32_t rank = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kKeys; k++) {
+        const unsigned long long b = __ballot(key == k);
+        if (key == k) rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) lens[wib * kWave + k] = (uint16_t)__popcll(b);
+      }
+      __syncthreads();
+      uint32_t pos = rank;
+      n_idle = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)(kBlock / kWave); w++) {
+#pragma unroll
+        for (uint32_t k = 0; k < kKeys; k++) {
+          const uint32_t c = lens[w * kWave + k];
+          if (k < key || (k == key && w < wib)) pos += c;
+          if (k == kKeys - 1) n_idle += c;
+        }
+      }
+      uint64_t* const xg = A.xchg + (size_t)blockIdx.x * kBlock * 8;
+      {
+        uint64_t* const xo = xg + pos;
+        xo[0] = __builtin_bit_cast(uint64_t, S.o.x); xo[kBlock] = __builtin_bit_cast(uint64_t, S.o.y); xo[2 * kBlock] = __builtin_bit_cast(uint64_t, S.o.z);
+        xo[3 * kBlock] = __builtin_bit_cast(uint64_t, S.d.x); xo[4 * kBlock] = __builtin_bit_cast(uint64_t, S.d.y); xo[5 * kBlock] = __builtin_bit_cast(uint64_t, S.d.z);
+        xo[6 * kBlock] = (uint64_t)__float_as_uint(S.t_stop) | ((uint64_t)S.pix << 32);
+        xo[7 * kBlock] = (uint64_t)S.st;
+      }
+      __syncthreads();  // (the counts are not read after this barrier, the traversal may overwrite them)
+      {
+        const uint64_t* const xi = xg + tid;
+        S.o = {__builtin_bit_cast(double, xi[0]), __builtin_bit_cast(double, xi[kBlock]), __builtin_bit_cast(double, xi[2 * kBlock])};
+        S.d = {__builtin_bit_cast(double, xi[3 * kBlock]), __builtin_bit_cast(double, xi[4 * kBlock]), __builtin_bit_cast(double, xi[5 * kBlock])};
+        const uint64_t tp = xi[6 * kBlock];
+        S.t_stop = __uint_as_float((uint32_t)tp);
+        S.pix = (uint32_t)(tp >> 32);
+        S.st = (uint32_t)xi[7 * kBlock];
+      }
+      // (the next round's states are written after its first barrier, which no wave passes before every wave has read these)
+    }
     // ---- hand new pixels to idle lanes
     unsigned long long idle = __ballot(st_kind(S.st) == kIdle);
     if constexpr (kShared) {
@@ -637,7 +693,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         }
       }
     }
-    while (!shared && (uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more)) {
+    while (!shared && (uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more) &&
+           (!kRegroup || !(A.regroup_mode & 4u) || n_idle == (uint32_t)kBlock)) {  // (regrouping, bit 2: new tiles only when the whole block is idle)
       if (tile_left == 0) {
         bool none = false;
         if (batch_pos == batch_end) {
@@ -695,9 +752,15 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       n_primary += (uint32_t)__popcll(idle & ~idle_now);
       idle = idle_now;
     }
+    if constexpr (kRegroup) {
+      // the whole block was idle before the hand-out above: did any wave get a tile?  (the same answer in all four)
+      if (n_idle == (uint32_t)kBlock && !__syncthreads_or(__ballot(st_kind(S.st) != kIdle) != 0ull)) break;
+      if (!__ballot(st_kind(S.st) != kIdle)) continue;  // a wave of idle lanes with no tile to take: on to the next round's barriers
+    } else {
     if (!__ballot(st_kind(S.st) != kIdle)) {
       if (shared) continue;  // a shared tile of padding slots only: on to the next one
       break;  // nothing in flight and nothing left to hand out
+    }
     }
     DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
          dg.lanes += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
@@ -747,7 +810,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
     if (st_kind(S.st) != kIdle && (!shared || wib == 0)) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
-      S = after_traversal<kLdsCtx>(S, h.dist, hm, shade_args, &events);
+      S = after_traversal<kLdsCtx, kRegroup>(S, h.dist, hm, shade_args, &events);
     }
     if constexpr (kShared) {
       if (shared) {
@@ -1028,6 +1091,7 @@ void free_workspace(DeviceScene* s) {
   (void)hipFree(s->d_tile_order_rest);
   (void)hipFree(s->d_tile_batch_rest);
   (void)hipFree(s->d_tiles_shared);
+  (void)hipFree(s->d_xchg);
   if (s->h_staging) (void)hipHostFree(s->h_staging);
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
@@ -1241,7 +1305,7 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     hipDeviceProp_t q;
     HIP_TRY(hipGetDeviceProperties(&q, device));
     int b = 1;
-    if (lens_bytes <= 64 * 1024) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true, false>, kBlock, lens_bytes));
+    if (lens_bytes <= 64 * 1024) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, render_kernel<true, 0>, kBlock, lens_bytes));
     out->dev_cus = q.multiProcessorCount;
     out->dev_lds_block = q.sharedMemPerBlock;
     out->dev_lds_cu = q.maxSharedMemoryPerMultiProcessor;
@@ -1272,6 +1336,7 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.ev_slots_alloc = s->ev_slots_alloc; spare.ctx_fields_alloc = s->ctx_fields_alloc;
   spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img;
   spare.d_tile_order_rest = s->d_tile_order_rest; spare.d_tile_batch_rest = s->d_tile_batch_rest; spare.d_tiles_shared = s->d_tiles_shared;
+  spare.d_xchg = s->d_xchg; spare.xchg_blocks = s->xchg_blocks;
   spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
@@ -1337,6 +1402,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->rays_primary = stats->rays_shadow = stats->rays_reflect = stats->hits = 0;
     stats->kernel_ms = 0.0;
     stats->tiles_shared = 0;
+    stats->handout_way = 0;
   }
   if (rows == 0) return "";
 
@@ -1465,13 +1531,26 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   static const bool no_order_env = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
   // (a call that must not allocate neither learns a hand-out order nor uses one: the tables are allocations)
   const bool no_order = no_order_env || no_alloc;
-  const int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 3 ? s->order_state : s->order_state == 4 ? s->order_way : 0;
-  A.tile_order = way == 1 ? (const uint32_t*)s->d_tile_order : way == 3 ? (const uint32_t*)s->d_tile_order_rest : nullptr;
-  A.batch_start = way == 1 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img
+  const int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 4 ? s->order_state : s->order_state == 5 ? s->order_way : 0;
+  A.tile_order = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_order : way == 3 ? (const uint32_t*)s->d_tile_order_rest : nullptr;
+  A.batch_start = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img
                   : way == 3 ? (const uint32_t*)s->d_tile_batch_rest : nullptr;
   A.n_tiles = (uint32_t)n_tiles;
   A.stride = 1;
-  A.n_batches = way == 1 ? s->n_batches : way == 2 ? s->n_batches_img : way == 3 ? s->n_batches_rest : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  A.n_batches = way == 1 || way == 4 ? s->n_batches : way == 2 ? s->n_batches_img : way == 3 ? s->n_batches_rest
+                : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  A.xchg = nullptr;
+  if (way == 4) {
+    if (s->xchg_blocks < grid) {
+      (void)hipFree(s->d_xchg);
+      s->d_xchg = nullptr;
+      s->xchg_blocks = 0;
+      HIP_TRY(hipMalloc(&s->d_xchg, (size_t)grid * kBlock * 8 * sizeof(uint64_t)));
+      s->xchg_blocks = grid;
+    }
+    A.xchg = (uint64_t*)s->d_xchg;
+    A.regroup_mode = [] { const char* e = std::getenv("GMLRT_REGROUP_MODE"); return e ? (uint32_t)std::atoi(e) : 0u; }();  // tuning runs
+  }
   A.tiles_shared = way == 3 ? (const uint32_t*)s->d_tiles_shared : nullptr;
   A.n_tiles_shared = way == 3 ? s->n_tiles_shared : 0u;
   for (uint32_t k = 0; k < kProgSlices; k++) A.slice_off[k] = s->slice_off[k];
@@ -1536,14 +1615,17 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   std::memcpy(s->h_staging, &SA, sizeof(SA));
   HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, kOffBlockCounts - kOffShadeArgs, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
-  if (A.lds_ctx && A.n_tiles_shared)
-    hipLaunchKernelGGL((render_kernel<true, true>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+  if (A.lds_ctx && A.xchg)
+    hipLaunchKernelGGL((render_kernel<true, 2>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                       d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
+  else if (A.lds_ctx && A.n_tiles_shared)
+    hipLaunchKernelGGL((render_kernel<true, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   else if (A.lds_ctx)
-    hipLaunchKernelGGL((render_kernel<true, false>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+    hipLaunchKernelGGL((render_kernel<true, 0>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   else
-    hipLaunchKernelGGL((render_kernel<false, false>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+    hipLaunchKernelGGL((render_kernel<false, 0>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
@@ -1559,7 +1641,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)s->ev_start, (hipEvent_t)s->ev_stop));
   if (no_alloc) {
     // nothing to learn and nothing to record
-  } else if (s->order_state >= 1 && s->order_state <= 3 && way == s->order_state) {
+  } else if (s->order_state >= 1 && s->order_state <= 4 && way == s->order_state) {
     // a trial: the learnt order trades cache locality between neighbouring waves for a shorter tail (scenes
     // with evenly priced tiles lose); the batch table over the image order only saves atomics; sharing the
     // dearest tiles among the waves of a block costs total work and pays when those tiles set the launch's length
@@ -1575,16 +1657,21 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
                    s->learnt_cost[list[list.size() / 2]] / 100.0, now[list[list.size() / 2]] / 100.0);
     }
     s->order_state++;
-    if (s->order_state == 3 && s->n_tiles_shared == 0) s->order_state = 4;  // no tile dear enough: nothing to try
-    if (s->order_state == 4) {
+    if (s->order_state == 3 && s->n_tiles_shared == 0) { s->order_state = 4; s->order_ms[3] = 0.f; }  // no tile dear enough: nothing to try
+    // The kernel that regroups the rays of a block is on trial only on request: it has lost on every scene measured
+    // (1.7 to 2.7 times slower: two block barriers a round put the four waves in step, and each round then lasts as
+    // long as its slowest wave), so a handle does not spend a launch on it unasked.
+    const bool regroup_rays = [] { const char* e = std::getenv("GMLRT_REGROUP_RAYS"); return e && *e == '1'; }();
+    if (s->order_state == 4 && !(A.lds_ctx && regroup_rays)) { s->order_state = 5; s->order_ms[4] = 0.f; }
+    if (s->order_state == 5) {
       s->order_way = 0;
       float best = 0.98f * s->order_ms[0];
-      for (int k = 1; k <= (s->n_tiles_shared ? 3 : 2); k++)
-        if (s->order_ms[k] < best) { best = s->order_ms[k]; s->order_way = k; }
+      for (int k = 1; k <= 4; k++)
+        if (s->order_ms[k] > 0.f && s->order_ms[k] < best) { best = s->order_ms[k]; s->order_way = k; }
       if (std::getenv("GMLRT_VERBOSE"))
         std::fprintf(stderr, "[gmlrt] tile hand-out: no costs known %.3f ms, learnt order %.3f ms, image order with batch table %.3f ms, "
-                     "learnt order with %u shared tiles %.3f ms -> way %d\n",
-                     s->order_ms[0], s->order_ms[1], s->order_ms[2], s->n_tiles_shared, s->order_ms[3], s->order_way);
+                     "learnt order with %u shared tiles %.3f ms, learnt order with the rays of a block regrouped %.3f ms -> way %d\n",
+                     s->order_ms[0], s->order_ms[1], s->order_ms[2], s->n_tiles_shared, s->order_ms[3], s->order_ms[4], s->order_way);
     }
   } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
     // first launch with this geometry: turn its per-tile costs into the order of the next ones
@@ -1790,6 +1877,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     stats->hits = counts[3];
     stats->kernel_ms = (double)ms;
     stats->tiles_shared = A.n_tiles_shared;
+    stats->handout_way = (uint32_t)way;
     stats->surface_errors = *(const uint32_t*)((const uint8_t*)s->h_staging + 1024 - 8) ? 1u : 0u;
   }
   return "";

@@ -41,13 +41,18 @@ __device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD
 // The lane's context record and its slice of the block's LDS region are found from the thread's own position
 // (ShadeArgs has the bases): as arguments they would be four more registers, and arguments beyond what the
 // calling convention passes in registers travel through scratch memory at every call.
-template <bool kLds>
+//
+// kSlot: rays change lanes between traversals (the kernel that regroups the rays of a block), so the context belongs to
+// the ray, not to the lane: bits 31..24 of S.st name the block's context slot the ray owns, and that slot takes the place
+// of the thread's position in every address below.  The bits are handed back unchanged.
+template <bool kLds, bool kSlot>
 __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
                                                   const ShadeArgs* __restrict__ SA_v, uint32_t* __restrict__ events_out) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
   extern __shared__ __align__(16) uint16_t lens[];
-  uint64_t* const vm_fast_v = (uint64_t*)((uint8_t*)lens + SA->vm_lds_off) + threadIdx.x;
-  double* const ctx_v = SA->ctx + ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * SA->ctx_fields * kWave + (threadIdx.x & (kWave - 1));
+  const uint32_t my = kSlot ? (S.st >> 24) : threadIdx.x;
+  uint64_t* const vm_fast_v = (uint64_t*)((uint8_t*)lens + SA->vm_lds_off) + my;
+  double* const ctx_v = SA->ctx + ((size_t)blockIdx.x * (kBlock / kWave) + my / kWave) * SA->ctx_fields * kWave + (my & (kWave - 1));
   double* __restrict__ ctx = global_space(ctx_v);
   constexpr size_t kHotStride = kLds ? (size_t)kBlock : (size_t)kWave;
   double* hot;
@@ -270,6 +275,6 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
          dq[5] += tq6 - tq5; dq[6] += tq_runs; dq[7] += tq_lanes;
        })
   *events_out = events;
-  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13);
+  S.st = (uint32_t)kind | ((uint32_t)level << 2) | (li << 13) | (kSlot ? my << 24 : 0u);
   return S;
 }

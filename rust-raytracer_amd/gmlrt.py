@@ -32,13 +32,13 @@ class Params(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("rays_primary", ctypes.c_uint64), ("rays_shadow", ctypes.c_uint64), ("rays_reflect", ctypes.c_uint64),
-                ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("tiles_shared", ctypes.c_uint64),
+                ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("tiles_shared", ctypes.c_uint32), ("handout_way", ctypes.c_uint32),
                 ("hits", ctypes.c_uint64), ("n_gpus", ctypes.c_uint32), ("surface_errors", ctypes.c_uint32)]
 
     def as_dict(self):
         return {"primary": self.rays_primary, "shadow": self.rays_shadow, "reflect": self.rays_reflect,
                 "kernel_ms": self.kernel_ms, "total_ms": self.total_ms, "hits": self.hits,
-                "n_gpus": self.n_gpus, "tiles_shared": self.tiles_shared, "surface_errors": self.surface_errors}
+                "n_gpus": self.n_gpus, "tiles_shared": self.tiles_shared, "handout_way": self.handout_way, "surface_errors": self.surface_errors}
 
     @property
     def rays(self):

@@ -144,6 +144,35 @@ def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, name, s
             os.environ["GMLRT_SHARED_TILE_SHARE"] = old
 
 
+@pytest.mark.parametrize("name,size,depth,mode", [("chess", (1921, 1081), 5, "0"), ("chess", (1920, 1080), 3, "5"),
+                                                  ("fractal", (1920, 1080), 3, "2"), ("spotlight", (1920, 1080), 4, "1")])
+def test_regrouping_the_rays_of_a_block_gives_the_same_image(gmlrt, name, size, depth, mode):
+    # The kernel that sorts a block's 256 rays into its four waves before every traversal (a ray changes lanes and
+    # takes its state and the number of its context slot along) is tried by a handle only on request; every way of
+    # sorting and both ways of taking new tiles must give the bytes and the ray counts of the ordinary kernel.
+    import torch
+    call = gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].with_overrides(size[0], size[1], depth)
+    ref, _, st_ref = gmlrt.render(call)
+    os.environ["GMLRT_REGROUP_RAYS"] = "1"
+    os.environ["GMLRT_REGROUP_MODE"] = mode
+    try:
+        scene = gmlrt.DeviceScene(call.blob, 0)
+        buf = torch.empty((size[1], size[0], 3), dtype=torch.uint8, device="cuda:0")
+        ways = []
+        for launch in range(6):  # 0 times the tiles, 1 and 2 try two orders, (3: no tile dear enough here,) the next one regroups
+            buf.fill_(0x5A)
+            st = scene.render_into(call.params, buf.data_ptr())
+            ways.append(st.handout_way)
+            assert (buf.cpu().numpy() == ref).all(), (name, launch)
+            assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits) == \
+                   (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits), (name, launch)
+        scene.close()
+        assert 4 in ways, ways
+    finally:
+        for k in ("GMLRT_REGROUP_RAYS", "GMLRT_REGROUP_MODE"):
+            os.environ.pop(k, None)
+
+
 def test_repeated_render_is_deterministic(gmlrt):
     prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
     a, _, sa = gmlrt.render(prog.calls[0])
