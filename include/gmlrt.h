@@ -226,10 +226,12 @@ void gmlrt_scene_destroy(gmlrt_scene* s);
  * may be NULL).  Work is queued on `hip_stream` (a hipStream_t, NULL = default
  * stream) and the call returns after the kernel has finished; stats as above.
  * A handle tunes itself to the frames it is asked for: the first call with a given
- * size, depth, field of view and partition times the pixel tiles, the second and third
- * try two other orders of handing them out, and from the fourth on the fastest is used
- * (on a frame whose tiles differ much in cost the first call takes up to 1.7 times as
- * long as the later ones).  The images are the same whatever the order. */
+ * size, depth, field of view and partition times the pixel tiles, the next two or three
+ * try other ways of handing them out (the dearest first; cost-balanced batches in image
+ * order; when single tiles are dear enough to set the length of the launch, those tiles
+ * rendered first by four waves each), and from then on the fastest is used (on a frame
+ * whose tiles differ much in cost the first call takes up to 1.7 times as long as the
+ * later ones).  The images are the same whichever way; gmlrt_stats.handout_way names it. */
 int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
                         void* hip_stream, gmlrt_stats* stats);
 
