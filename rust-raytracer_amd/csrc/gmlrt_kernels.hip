@@ -28,6 +28,7 @@
 #include <vector>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 
 #include "gmlrt_device.hpp"
@@ -115,6 +116,7 @@ struct KArgs {
   // program slice of each wave of the block starts.
   const uint32_t* tiles_shared;
   uint32_t n_tiles_shared;
+  uint32_t tail_lds_off;           // byte offset of two LDS words for sharing the last tiles of a launch; 0: not done
   uint32_t regroup_mode;           // bits 1..0: what the rays are sorted by (tuning); bit 2: new tiles only for an idle block
   uint64_t* xchg;                  // the regrouping kernel: 256 x 8 words per block, the ray states on their way to their new lanes
   uint32_t slice_off[kProgSlices];
@@ -615,12 +617,50 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   // the same in all four waves (the list position, and ray states that are copies of wave 0's), so the block's
   // barriers are met by all of them.  The exchange goes through the hot-context slots of the lanes of waves 1-3,
   // which hold nothing while those waves run no per-ray code: field f of thread t is xq[f * 256 + t].
+  //
+  // The same protocol serves the END of a launch without any list (A.tail_lds_off != 0): a wave that finds nothing
+  // left to hand out counts itself in (an LDS counter) and waits at a block barrier; a wave that still traces and
+  // sees the other three counted in joins them at that barrier and becomes the owner: from then on the four trace
+  // the owner's rays together, its remaining tiles included.  (All four counted in: everybody leaves.)  The last
+  // tiles of a launch, which a single wave would trail behind an idle device, take a third of the time.
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane(tid / kWave);
   uint32_t shared_next = blockIdx.x;
-  bool shared = false;
+  bool shared = false;   // this wave traces rays that all four waves of the block hold
+  bool tail = false;     // ... because the block has gone over to sharing its last busy wave's work
+  bool owner = false;    // this wave runs the per-ray code and hands out the rays
+  uint32_t owner_wib = 0;
   uint32_t pc0 = 0, shared_tile = 0;
   DIAGS(unsigned long long ds_phase[4] = {0, 0, 0, 0}, ds_t = 0;)
   [[maybe_unused]] double* const xq = (double*)((uint8_t*)lens + A.vm_lds_off);
+  // [0] waves that have run out of work, [1] the owner's number
+  [[maybe_unused]] volatile uint32_t* const tailc = (volatile uint32_t*)((uint8_t*)lens + A.tail_lds_off);
+  if constexpr (kShared) {
+    if (A.tail_lds_off) {
+      if (tid == 0) { tailc[0] = 0; tailc[1] = 0; }
+      __syncthreads();
+    }
+  }
+// the owner's rays to the other three, through fields 2..9 of the lanes of the wave after the owner (one of the three:
+// its context slots hold nothing); a block barrier between the writing and the reading
+#define GMLRT_HAND_OUT_RAYS()                                                                               \
+  do {                                                                                                      \
+    double* const xs = xq + 2 * kBlock + ((owner_wib + 1u) & 3u) * kWave + lane;                            \
+    if (owner) {                                                                                            \
+      xs[0] = S.o.x; xs[kBlock] = S.o.y; xs[2 * kBlock] = S.o.z;                                            \
+      xs[3 * kBlock] = S.d.x; xs[4 * kBlock] = S.d.y; xs[5 * kBlock] = S.d.z;                               \
+      ((uint64_t*)xs)[6 * kBlock] = (uint64_t)__float_as_uint(S.t_stop) | ((uint64_t)S.pix << 32);          \
+      ((uint64_t*)xs)[7 * kBlock] = (uint64_t)S.st;                                                         \
+    }                                                                                                       \
+    __syncthreads();                                                                                        \
+    if (!owner) {                                                                                           \
+      S.o = {xs[0], xs[kBlock], xs[2 * kBlock]};                                                            \
+      S.d = {xs[3 * kBlock], xs[4 * kBlock], xs[5 * kBlock]};                                               \
+      const uint64_t tp = ((uint64_t*)xs)[6 * kBlock];                                                      \
+      S.t_stop = __uint_as_float((uint32_t)tp);                                                             \
+      S.pix = (uint32_t)(tp >> 32);                                                                         \
+      S.st = (uint32_t)((uint64_t*)xs)[7 * kBlock];                                                         \
+    }                                                                                                       \
+  } while (0)
 
   [[maybe_unused]] uint32_t n_idle = 0;  // regrouping: idle lanes of the whole block
   for (;;) {
@@ -677,23 +717,36 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     }
     // ---- hand new pixels to idle lanes
     unsigned long long idle = __ballot(st_kind(S.st) == kIdle);
+    [[maybe_unused]] const unsigned long long idle_at_top = idle;
     if constexpr (kShared) {
-      if ((shared || shared_next < A.n_tiles_shared) && idle == ~0ull) {
+      if (!tail && (shared || shared_next < A.n_tiles_shared) && idle == ~0ull) {
         if (shared && A.tile_cost && tid == 0) A.tile_cost[shared_tile] = (uint32_t)(wall_clock64() - tile_t0);
         shared = shared_next < A.n_tiles_shared;
         pc0 = 0;
+        owner = false;
         if (shared) {
           shared_tile = A.tiles_shared[shared_next];
           if (A.tile_cost) tile_t0 = wall_clock64();
           GMLRT_CAMERA_RAY(shared_tile, (uint32_t)lane);
           shared_next += gridDim.x;
           pc0 = A.slice_off[wib];
+          owner = wib == 0;
+          owner_wib = 0;
           idle = __ballot(st_kind(S.st) == kIdle);
-          if (wib == 0) n_primary += (uint32_t)__popcll(~idle);
+          if (owner) n_primary += (uint32_t)__popcll(~idle);
         }
       }
+      // the other three waves of the block have run out of work and wait: share what this one still has
+      if (A.tail_lds_off && !shared && idle != ~0ull && (uint32_t)__builtin_amdgcn_readfirstlane((int)tailc[0]) == 3u) {
+        if (lane == 0) tailc[1] = wib;
+        __syncthreads();  // the barrier the other three wait at
+        tail = shared = owner = true;
+        owner_wib = wib;
+        pc0 = A.slice_off[0];
+        GMLRT_HAND_OUT_RAYS();
+      }
     }
-    while (!shared && (uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more) &&
+    while ((!shared || (tail && owner)) && (uint32_t)__popcll(idle) >= (uint32_t)GMLRT_REFILL_MIN && (tile_left || more) &&
            (!kRegroup || !(A.regroup_mode & 4u) || n_idle == (uint32_t)kBlock)) {  // (regrouping, bit 2: new tiles only when the whole block is idle)
       if (tile_left == 0) {
         bool none = false;
@@ -757,9 +810,33 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       if (n_idle == (uint32_t)kBlock && !__syncthreads_or(__ballot(st_kind(S.st) != kIdle) != 0ull)) break;
       if (!__ballot(st_kind(S.st) != kIdle)) continue;  // a wave of idle lanes with no tile to take: on to the next round's barriers
     } else {
+    if constexpr (kShared) {
+      if (tail && idle_at_top == ~0ull) {
+        // the shared rays are all done (the same in all four waves): the owner has looked for another tile of its own
+        // above; what it found goes to the others, and if it found nothing everybody leaves
+        GMLRT_HAND_OUT_RAYS();
+        if (!__ballot(st_kind(S.st) != kIdle)) break;
+      }
+    }
     if (!__ballot(st_kind(S.st) != kIdle)) {
-      if (shared) continue;  // a shared tile of padding slots only: on to the next one
-      break;  // nothing in flight and nothing left to hand out
+      if (shared && !tail) continue;  // a shared tile of padding slots only: on to the next one
+      if constexpr (kShared) {
+        if (A.tail_lds_off && !tail) {
+          // nothing in flight and nothing left to hand out: count this wave in and wait for the rest of the block
+          if (lane == 0) atomicAdd((uint32_t*)tailc, 1u);
+          __syncthreads();
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tailc[0]) == (uint32_t)(kBlock / kWave)) break;  // all four: done
+          tail = shared = true;
+          owner = false;
+          owner_wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)tailc[1]);
+          pc0 = A.slice_off[(wib - owner_wib) & 3u];
+          GMLRT_HAND_OUT_RAYS();  // (the owner still traces, or it would have counted itself in: some lane is active now)
+        } else {
+          break;
+        }
+      } else {
+        break;  // nothing in flight and nothing left to hand out
+      }
     }
     }
     DIAG(unsigned long long t1 = __builtin_readcyclecounter(); dg.t_refill += t1 - t0; dg.n_trav++;
@@ -778,15 +855,16 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         // then at or before the light too, which is all the light test asks)
         uint64_t* const xm = (uint64_t*)xq + kBlock;
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[0] += n_ - ds_t; ds_t = n_; })
-        if (wib != 0) {
+        if (!owner) {
           xq[tid] = h.dist;
           xm[tid] = (uint64_t)(h.meta | (h.any ? kHitAny : 0u)) | (h.redo ? 1ull << 32 : 0ull);
           h.redo = false;
         }
         __syncthreads();
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[1] += n_ - ds_t; ds_t = n_; })
-        if (wib == 0) {
-          for (int w = 1; w < kBlock / kWave; w++) {
+        if (owner) {
+          for (uint32_t k = 1; k < (uint32_t)(kBlock / kWave); k++) {
+            const uint32_t w = (owner_wib + k) & 3u;
             const double dw = xq[w * kWave + lane];
             const uint64_t mw = xm[w * kWave + lane];
             if (mw >> 32) h.redo = true;
@@ -808,31 +886,15 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     DIAG(unsigned long long t2 = __builtin_readcyclecounter(); dg.t_trav += t2 - t1;
          dg.k_trav[dk]++; dg.k_leaf[dk] += dg.n_leaf - dk_leaf0;)
     uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
-    if (st_kind(S.st) != kIdle && (!shared || wib == 0)) {
+    if (st_kind(S.st) != kIdle && (!shared || owner)) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
       S = after_traversal<kLdsCtx, kRegroup>(S, h.dist, hm, shade_args, &events);
     }
     if constexpr (kShared) {
       if (shared) {
-        // wave 0's next rays to the other three (fields 2..9 of wave 1's lanes)
-        double* const xs = xq + 2 * kBlock + kWave + lane;
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[2] += n_ - ds_t; ds_t = n_; })
-        if (wib == 0) {
-          xs[0] = S.o.x; xs[kBlock] = S.o.y; xs[2 * kBlock] = S.o.z;
-          xs[3 * kBlock] = S.d.x; xs[4 * kBlock] = S.d.y; xs[5 * kBlock] = S.d.z;
-          ((uint64_t*)xs)[6 * kBlock] = (uint64_t)__float_as_uint(S.t_stop) | ((uint64_t)S.pix << 32);
-          ((uint64_t*)xs)[7 * kBlock] = (uint64_t)S.st;
-        }
-        __syncthreads();
+        GMLRT_HAND_OUT_RAYS();
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[3] += n_ - ds_t; ds_t = n_; })
-        if (wib != 0) {
-          S.o = {xs[0], xs[kBlock], xs[2 * kBlock]};
-          S.d = {xs[3 * kBlock], xs[4 * kBlock], xs[5 * kBlock]};
-          const uint64_t tp = ((uint64_t*)xs)[6 * kBlock];
-          S.t_stop = __uint_as_float((uint32_t)tp);
-          S.pix = (uint32_t)(tp >> 32);
-          S.st = (uint32_t)((uint64_t*)xs)[7 * kBlock];
-        }
         // (the next round's candidates go to fields 0 and 1, its rays are written after the barrier that
         // follows them: nothing here is overwritten while a wave may still read it)
       }
@@ -1257,7 +1319,11 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   {
     uint32_t need_stack = 1;
     uint64_t need_events = 2;
+    const auto t_derive0 = std::chrono::steady_clock::now();
     std::vector<uint8_t> prog = derive_stream_program(blob, &need_stack, &need_events, out->slice_off);
+    if (std::getenv("GMLRT_VERBOSE"))
+      std::fprintf(stderr, "[gmlrt] traversal program derived in %.3f ms\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_derive0).count());
     out->max_stack = std::max(out->hdr.max_stack, need_stack);
     out->max_events = std::max<uint64_t>(out->hdr.max_events, need_events);
     if (out->max_events > 0xFFFFFFFFull) return "too large: event stack";
@@ -1423,15 +1489,17 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   }
   // With room for all of them the hot context fields go to LDS as well, into the same region.
   const size_t hot_bytes = (size_t)kHotFields * kBlock * sizeof(double);
+  size_t lds_spare = 0;  // bytes of the block's LDS share that nothing uses
   {
     const size_t per_block = (size_t)prop.sharedMemPerBlock < (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu
                                  ? (size_t)prop.sharedMemPerBlock
                                  : (size_t)prop.maxSharedMemoryPerMultiProcessor / blocks_per_cu;
     A.lds_ctx = lens_bytes + hot_bytes <= per_block ? 1u : 0u;
+    lds_spare = A.lds_ctx ? per_block - lens_bytes - hot_bytes : 0;
   }
   // (six of the region's slots are kept for the programs' results: gmlrt_shade.hpp)
   if (A.lds_ctx) n_vm_fast = s->n_vm_regs < (uint32_t)kHotFields - 6u ? s->n_vm_regs : (uint32_t)kHotFields - 6u;
-  const size_t lds_bytes = lens_bytes + (A.lds_ctx ? hot_bytes : n_vm_fast * kBlock * sizeof(uint64_t));
+  size_t lds_bytes = lens_bytes + (A.lds_ctx ? hot_bytes : n_vm_fast * kBlock * sizeof(uint64_t));
   A.n_vm_fast = (uint32_t)n_vm_fast;
   A.vm_lds_off = (uint32_t)lens_bytes;
   uint64_t grid = (uint64_t)prop.multiProcessorCount * (uint64_t)blocks_per_cu;
@@ -1539,6 +1607,18 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.stride = 1;
   A.n_batches = way == 1 || way == 4 ? s->n_batches : way == 2 ? s->n_batches_img : way == 3 ? s->n_batches_rest
                 : (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+  // The end of a launch shared among the waves of a block (see the kernel): for launches that know no tile costs and
+  // are not there to measure them (a frame rendered once ends on whatever dear tile came up last), and together with
+  // the shared tiles of way 3.  Needs the frontier's slices, the LDS context region and 16 spare bytes of LDS.
+  A.tail_lds_off = 0;
+  {
+    const bool tail_share = [] { const char* e = std::getenv("GMLRT_TAIL_SHARE"); return !(e && *e == '0'); }();  // tuning runs
+    const bool timing = s->order_state == 0 && !no_order && s->learn_order;
+    if (tail_share && A.lds_ctx && s->slice_off[0] != 0 && lds_spare >= 16 && ((way == 0 && !timing) || way == 3)) {
+      A.tail_lds_off = (uint32_t)lds_bytes;
+      lds_bytes += 16;
+    }
+  }
   A.xchg = nullptr;
   if (way == 4) {
     if (s->xchg_blocks < grid) {
@@ -1618,7 +1698,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   if (A.lds_ctx && A.xchg)
     hipLaunchKernelGGL((render_kernel<true, 2>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
-  else if (A.lds_ctx && A.n_tiles_shared)
+  else if (A.lds_ctx && (A.n_tiles_shared || A.tail_lds_off))
     hipLaunchKernelGGL((render_kernel<true, 1>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
   else if (A.lds_ctx)

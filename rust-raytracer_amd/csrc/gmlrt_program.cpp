@@ -25,6 +25,7 @@
 //    wave-uniform address gives everything a step needs in a single round of scalar
 //    loads instead of word -> index -> record.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -234,6 +235,13 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     ref_area = smaller_area(all);
     if (!std::isfinite(ref_area)) ref_area = 0.0;
   }
+  // centres of the frontier children's boxes (the sorts below compare them many times)
+  std::vector<double> cent(tree.size() * 3, 0.0);
+  for (int ni : items)
+    if (tree[(size_t)ni].bound >= 0) {
+      const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
+      for (int k = 0; k < 3; k++) cent[(size_t)ni * 3 + (size_t)k] = 0.5 * (g.lo[k] + g.hi[k]);
+    }
   std::vector<size_t> skip_open;  // skip records waiting for the offset of the record after their operator
   auto emit_item = [&](int ni) {
     const PNode& n = tree[(size_t)ni];
@@ -367,10 +375,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     }
   }
   struct Range { size_t lo, hi; int stage; size_t bound_at; };
-  auto centroid = [&](int ni, int axis) {
-    const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
-    return 0.5 * (g.lo[axis] + g.hi[axis]);
-  };
+  auto centroid = [&](int ni, int axis) { return cent[(size_t)ni * 3 + (size_t)axis]; };
   const double cam[3] = {0.0, 0.0, -1.0};  // raytracer.rs:138
   std::vector<Range> ranges;
   ranges.push_back({0, grouped.size(), 0, 0});
@@ -469,13 +474,16 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   };
 
   // emit both, keep the one with the smaller expected number of bound tests
+  const auto t_a = std::chrono::steady_clock::now();
   emit_as_given();
+  const auto t_b = std::chrono::steady_clock::now();
   const double cost_given = cost;
   std::vector<uint8_t> given;
   given.swap(S.bytes);
   cost = 0.0;
   open_p.clear();
   emit_regrouped(items);
+  const auto t_c = std::chrono::steady_clock::now();
   bool regroup = cost < cost_given;
   if (const char* e = std::getenv("GMLRT_REGROUP")) regroup = *e == '1';  // tuning runs
   if (std::getenv("GMLRT_VERBOSE"))
@@ -491,7 +499,8 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   // the waves; every slice gets its own hierarchy of boxes.  Offsets in a slice are offsets into the whole
   // buffer, like everywhere else.
   for (uint32_t k = 0; k < kProgSlices; k++) slice_off[k] = 0;
-  if (items.size() >= 2 * (size_t)kProgSlices && tree[(size_t)st[0]].nl >= 32) {
+  static const bool no_slices = std::getenv("GMLRT_NO_SLICES") != nullptr;  // tuning runs
+  if (!no_slices && items.size() >= 2 * (size_t)kProgSlices && tree[(size_t)st[0]].nl >= 32) {
     // spatial order: a walk through the emitted frontier, children in the order their first leaf appears
     std::vector<int> spatial;
     {
@@ -523,32 +532,35 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     // every ray: they are dealt round-robin.
     std::vector<std::vector<int>> deal(kProgSlices);
     {
+      struct Placed { double c[3], size2, nl; };
+      std::vector<std::vector<Placed>> placed(kProgSlices);
       std::vector<double> load(kProgSlices, 0.0);
       uint32_t rr = 0;
-      auto ctr = [&](int ni, double* c, double* size2) {
-        const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
-        *size2 = 0.0;
-        for (int k = 0; k < 3; k++) { c[k] = 0.5 * (g.lo[k] + g.hi[k]); const double e = g.hi[k] - g.lo[k]; *size2 += e * e; }
-        return std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(*size2);
-      };
       for (int ni : spatial) {
-        double c[3], s2;
-        // (quadratic in the number of children: a frontier of thousands is dealt round-robin in its spatial order)
-        if (spatial.size() > 2048 || tree[(size_t)ni].bound < 0 || !ctr(ni, c, &s2)) { deal[rr++ % kProgSlices].push_back(ni); continue; }
+        Placed me;
+        me.nl = (double)tree[(size_t)ni].nl;
+        bool finite = tree[(size_t)ni].bound >= 0;
+        if (finite) {
+          const gmlrt_bound& g = bounds[tree[(size_t)ni].bound];
+          me.size2 = 0.0;
+          for (int k = 0; k < 3; k++) { me.c[k] = 0.5 * (g.lo[k] + g.hi[k]); const double e = g.hi[k] - g.lo[k]; me.size2 += e * e; }
+          finite = std::isfinite(me.c[0]) && std::isfinite(me.c[1]) && std::isfinite(me.c[2]) && std::isfinite(me.size2);
+        }
+        // (quadratic in the number of children, a division each: a frontier of hundreds is dealt round-robin in its spatial order)
+        if (spatial.size() > 128 || !finite) { deal[rr++ % kProgSlices].push_back(ni); continue; }
         uint32_t best = 0;
         double best_v = INFINITY;
         for (uint32_t k = 0; k < kProgSlices; k++) {
           double v = 1e-9 * load[k];
-          for (int nj : deal[k]) {
-            double cj[3], sj;
-            if (tree[(size_t)nj].bound < 0 || !ctr(nj, cj, &sj)) continue;
-            const double d2 = (c[0] - cj[0]) * (c[0] - cj[0]) + (c[1] - cj[1]) * (c[1] - cj[1]) + (c[2] - cj[2]) * (c[2] - cj[2]);
-            v += (double)tree[(size_t)nj].nl / (d2 + 0.25 * (s2 + sj) + 1e-300);
+          for (const Placed& o : placed[k]) {
+            const double d2 = (me.c[0] - o.c[0]) * (me.c[0] - o.c[0]) + (me.c[1] - o.c[1]) * (me.c[1] - o.c[1]) + (me.c[2] - o.c[2]) * (me.c[2] - o.c[2]);
+            v += o.nl / (d2 + 0.25 * (me.size2 + o.size2) + 1e-300);
           }
           if (v < best_v) { best_v = v; best = k; }
         }
         deal[best].push_back(ni);
-        load[best] += (double)tree[(size_t)ni].nl;
+        placed[best].push_back(me);
+        load[best] += me.nl;
       }
     }
     for (uint32_t k = 0; k < kProgSlices; k++) {
@@ -567,6 +579,8 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     }
   }
   if (std::getenv("GMLRT_VERBOSE")) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[gmlrt] derivation: as given %.3f ms, regrouped %.3f ms, slices %.3f ms\n", ms(t_a, t_b), ms(t_b, t_c), ms(t_c, std::chrono::steady_clock::now()));
     size_t n_kind[8] = {0};
     for (size_t at = 0; at + 16 <= S.bytes.size();) {
       uint32_t kind;
