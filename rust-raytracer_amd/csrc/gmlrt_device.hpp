@@ -17,6 +17,7 @@ namespace gmlrt {
 constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5, kRecSkipEmpty = 6;
 constexpr uint32_t kOpSwapped = 0x10u;  // operator arg: the right operand was pushed first (ties still go to the left one)
 constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
+constexpr uint32_t kRecIsBox = 0x200u; // set in every kRecBox record and in no other (the traversal's loop over boxes tests this bit)
 struct ProgBound {   // 64 bytes
   uint32_t kind;
   uint32_t skip_to;  // byte offset of the first record after the bounded subtree

@@ -156,7 +156,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
       if (empty || box_area < box_bias() * sphere_area) {
         ProgBox r;
         std::memset(&r, 0, sizeof(r));
-        r.kind = kRecBox | (frontier ? kRecFlag : 0u);
+        r.kind = kRecBox | kRecIsBox | (frontier ? kRecFlag : 0u);
         // the slab test is symmetric in lo and hi, so an empty solid (lo > hi) is stated as a
         // point no ray of interest can reach
         for (int i = 0; i < 3; i++) {

@@ -78,41 +78,51 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     // the wave reads next: they get a loop of their own, whose only state is scalar.  (In one loop
     // with the other record kinds every bound record paid for copying the lanes' candidate, flags
     // and stack height from one iteration to the next.)
-    while (kind == kRecBox) {
-      // A bound in front of a subtree: if no lane's ray comes near it, every list below is
-      // empty.  Under the union frontier that means "nothing to take"; inside a frontier
-      // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
-      // not reproducible, so they use fused multiply-adds.  Any NaN compares false and keeps
-      // the subtree.  (Boxes are nearly all the bounds there are: the loop holds nothing else.)
-      // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
-      const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
-      const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
-      const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
-      const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
-                                        __builtin_fmaf(REC_F32(8), ie_z, oe_z));
-      const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
-      const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
-      const float tn_lo = tnear - err;  // no entry before this
-      const bool hit = (fl & kFlActive) && !(tfar + err < tn_lo)
+    // (The loop asks for a bit that only box records carry, not for the kind: a test of the kind is merged by the
+    // compiler with the dispatch on the kind below, and every box then pays for that dispatch.  Which lanes are
+    // active and which have a candidate does not change inside a run of boxes: those are wave masks set up once,
+    // and the test of a box is two vector compares whose masks are combined with scalar operations.)
+    if (kf & kRecIsBox) {
+      const unsigned long long m_active = __ballot((fl & kFlActive) != 0);
 #if GMLRT_TMAX_CULL
-                       && !((best_m & kHitAny) && (double)tn_lo > best)
+      const unsigned long long m_cand = __ballot((best_m & kHitAny) != 0);
 #endif
-          ;
-      DIAG(dg.n_bound++;)
-      DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
-      if (__ballot(hit)) {
-        DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(__ballot(hit));)
-        pc += (uint32_t)sizeof(ProgBox);
-      } else {
-        DIAG(dg.n_skip++;)
-        if (!(kf & kRecFlag)) {
-          lens[level * kBlock + tid] = 0;
-          level++;
+      do {
+        // A bound in front of a subtree: if no lane's ray comes near it, every list below is
+        // empty.  Under the union frontier that means "nothing to take"; inside a frontier
+        // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
+        // not reproducible, so they use fused multiply-adds.  Any NaN compares false and keeps
+        // the subtree.  (Boxes are nearly all the bounds there are: the loop holds nothing else.)
+        // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
+        const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
+        const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
+        const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
+        const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
+                                          __builtin_fmaf(REC_F32(8), ie_z, oe_z));
+        const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+        const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+        const float tn_lo = tnear - err;  // no entry before this
+        unsigned long long m_hit = __ballot(!(tfar + err < tn_lo)) & m_active;
+#if GMLRT_TMAX_CULL
+        m_hit &= ~(m_cand & __ballot((double)tn_lo > best));
+#endif
+        DIAG(dg.n_bound++;)
+        DIAG(dg.b_lanes += (unsigned long long)__popcll(m_hit);)
+        if (m_hit) {
+          DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(m_hit);)
+          pc += (uint32_t)sizeof(ProgBox);
+          R = *(const u32x16*)(const void*)(prog + pc);
+        } else {
+          DIAG(dg.n_skip++;)
+          if (!(kf & kRecFlag)) {
+            lens[level * kBlock + tid] = 0;
+            level++;
+          }
+          pc = R[1];
+          R = *(const u32x16*)(const void*)(prog + pc);
         }
-        pc = R[1];
-      }
-      R = *(const u32x16*)(const void*)(prog + pc);
-      kf = R[0];
+        kf = R[0];
+      } while (kf & kRecIsBox);
       kind = kf & 0xFu;
     }
     if (kind == kRecBound) {
