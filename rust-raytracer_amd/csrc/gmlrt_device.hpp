@@ -17,7 +17,11 @@ namespace gmlrt {
 constexpr uint32_t kRecEnd = 0, kRecBound = 1, kRecLeaf = 2, kRecOp = 3, kRecTake = 4, kRecBox = 5, kRecSkipEmpty = 6;
 constexpr uint32_t kOpSwapped = 0x10u;  // operator arg: the right operand was pushed first (ties still go to the left one)
 constexpr uint32_t kRecFlag = 0x100u;  // bound: under the union frontier (a skip pushes no list); leaf: frontier leaf
-constexpr uint32_t kRecIsBox = 0x200u; // set in every kRecBox record and in no other (the traversal's loop over boxes tests this bit)
+// One bit per record kind, beside the kind itself: the traversal asks for these bits one after the other, most frequent
+// kind first (a chain of tests of the kind would be turned into one dispatch by the compiler, with state flags and
+// a common exit that every record then walks through).  kRecEnd has none.
+constexpr uint32_t kRecIsBox = 0x200u, kRecIsLeaf = 0x400u, kRecIsOp = 0x800u, kRecIsTake = 0x1000u, kRecIsSkip = 0x2000u,
+                   kRecIsBound = 0x4000u;
 struct ProgBound {   // 64 bytes
   uint32_t kind;
   uint32_t skip_to;  // byte offset of the first record after the bounded subtree

@@ -174,7 +174,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
     }
     ProgBound r;
     std::memset(&r, 0, sizeof(r));
-    r.kind = kRecBound | (frontier ? kRecFlag : 0u);
+    r.kind = kRecBound | kRecIsBound | (frontier ? kRecFlag : 0u);
     r.skip_to = 0;  // patched when the subtree is complete
     for (int i = 0; i < 3; i++) r.center[i] = g.center[i];
     r.radius2 = g.radius * g.radius;
@@ -184,7 +184,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   auto put_leaf = [&](uint32_t leaf, bool take) {
     ProgLeaf r;
     std::memset(&r, 0, sizeof(r));
-    r.kind = kRecLeaf | (take ? kRecFlag : 0u) | (leaves[leaf].type << 16);
+    r.kind = kRecLeaf | kRecIsLeaf | (take ? kRecFlag : 0u) | (leaves[leaf].type << 16);
     r.leaf = leaf;
     std::memcpy(r.inv_m, leaves[leaf].inv_m, sizeof(r.inv_m));
     S.put(&r, sizeof(r));
@@ -192,7 +192,7 @@ std::vector<uint8_t> derive_stream_program(const void* blob, uint32_t* need_stac
   auto put_small = [&](uint32_t kind, uint32_t arg) {
     ProgSmall r;
     std::memset(&r, 0, sizeof(r));
-    r.kind = kind;
+    r.kind = kind | (kind == kRecOp ? kRecIsOp : kind == kRecTake ? kRecIsTake : kind == kRecSkipEmpty ? kRecIsSkip : 0u);
     r.arg = arg;
     S.put(&r, sizeof(r));
   };

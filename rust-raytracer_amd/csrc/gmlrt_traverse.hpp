@@ -72,7 +72,6 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     // per record.  (The program is padded so that this never reads past its buffer.)
     u32x16 R = *(const u32x16*)(const void*)(prog + pc);
     uint32_t kf = R[0];
-    uint32_t kind = kf & 0xFu;
     level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);  // wave-uniform by construction: say so
     // Bounds come in runs (the way down a hierarchy) and change nothing a lane carries, only where
     // the wave reads next: they get a loop of their own, whose only state is scalar.  (In one loop
@@ -80,9 +79,10 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     // and stack height from one iteration to the next.)
     // (The loop asks for a bit that only box records carry, not for the kind: a test of the kind is merged by the
     // compiler with the dispatch on the kind below, and every box then pays for that dispatch.  Which lanes are
-    // active and which have a candidate does not change inside a run of boxes: those are wave masks set up once,
-    // and the test of a box is two vector compares whose masks are combined with scalar operations.)
-    if (kf & kRecIsBox) {
+    // active and which have a candidate does not change inside a run of bounds: those are wave masks set up once,
+    // and the test of a bound is a few vector compares whose masks are combined with scalar operations.  Both
+    // kinds of bound record are the same size.)
+    if (kf & (kRecIsBox | kRecIsBound)) {
       const unsigned long long m_active = __ballot((fl & kFlActive) != 0);
 #if GMLRT_TMAX_CULL
       const unsigned long long m_cand = __ballot((best_m & kHitAny) != 0);
@@ -92,20 +92,35 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
         // empty.  Under the union frontier that means "nothing to take"; inside a frontier
         // child the subtree's (empty) list is pushed.  The tests only have to be conservative,
         // not reproducible, so they use fused multiply-adds.  Any NaN compares false and keeps
-        // the subtree.  (Boxes are nearly all the bounds there are: the loop holds nothing else.)
-        // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
-        const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
-        const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
-        const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
-        const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
-                                          __builtin_fmaf(REC_F32(8), ie_z, oe_z));
-        const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
-        const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
-        const float tn_lo = tnear - err;  // no entry before this
-        unsigned long long m_hit = __ballot(!(tfar + err < tn_lo)) & m_active;
+        // the subtree.
+        unsigned long long m_hit;
+        if (kf & kRecIsBox) {
+          // ProgBox: skip_to, (lo, hi) per axis in f32, largest magnitude per axis.  Slab test.
+          const float x1 = __builtin_fmaf(REC_F32(0), inv_x, noi_x), x2 = __builtin_fmaf(REC_F32(1), inv_x, noi_x);
+          const float y1 = __builtin_fmaf(REC_F32(2), inv_y, noi_y), y2 = __builtin_fmaf(REC_F32(3), inv_y, noi_y);
+          const float z1 = __builtin_fmaf(REC_F32(4), inv_z, noi_z), z2 = __builtin_fmaf(REC_F32(5), inv_z, noi_z);
+          const float err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(REC_F32(6), ie_x, oe_x), __builtin_fmaf(REC_F32(7), ie_y, oe_y)),
+                                            __builtin_fmaf(REC_F32(8), ie_z, oe_z));
+          const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+          const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+          const float tn_lo = tnear - err;  // no entry before this
+          m_hit = __ballot(!(tfar + err < tn_lo)) & m_active;
 #if GMLRT_TMAX_CULL
-        m_hit &= ~(m_cand & __ballot((double)tn_lo > best));
+          m_hit &= ~(m_cand & __ballot((double)tn_lo > best));
 #endif
+        } else {
+          // the same with the subtree's sphere.  ProgBound: skip_to, center[3], radius2, radius.  |perp|^2 =
+          // |oc|^2 - tca^2 (d has unit length); the slack added to r^2 covers the cancellation in that difference.
+          const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
+          const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
+          const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
+          const double r2 = REC_F64(3);
+          m_hit = m_active & ~__ballot(__builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2)) &
+                  ~(__ballot(tca < 0.0) & __ballot(oc2 > r2));
+#if GMLRT_TMAX_CULL
+          m_hit &= ~(m_cand & __ballot(tca - REC_F64(4) > best));
+#endif
+        }
         DIAG(dg.n_bound++;)
         DIAG(dg.b_lanes += (unsigned long long)__popcll(m_hit);)
         if (m_hit) {
@@ -122,37 +137,9 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
           R = *(const u32x16*)(const void*)(prog + pc);
         }
         kf = R[0];
-      } while (kf & kRecIsBox);
-      kind = kf & 0xFu;
+      } while (kf & (kRecIsBox | kRecIsBound));
     }
-    if (kind == kRecBound) {
-      // the same with the subtree's sphere.  ProgBound: skip_to, center[3], radius2, radius.  |perp|^2 =
-      // |oc|^2 - tca^2 (d has unit length); the slack added to r^2 covers the cancellation in that difference.
-      const double ocx = REC_F64(0) - o.x, ocy = REC_F64(1) - o.y, ocz = REC_F64(2) - o.z;
-      const double oc2 = __builtin_fma(ocx, ocx, __builtin_fma(ocy, ocy, ocz * ocz));
-      const double tca = __builtin_fma(ocx, d.x, __builtin_fma(ocy, d.y, ocz * d.z));
-      const double r2 = REC_F64(3);
-      const bool hit = (fl & kFlActive) && !(__builtin_fma(-tca, tca, oc2) > __builtin_fma(oc2, 1e-9, r2)) && !(tca < 0.0 && oc2 > r2)
-#if GMLRT_TMAX_CULL
-                       && !((best_m & kHitAny) && tca - REC_F64(4) > best)
-#endif
-          ;
-      DIAG(dg.n_bound++;)
-      DIAG(dg.b_lanes += (unsigned long long)__popcll(__ballot(hit));)
-      if (__ballot(hit)) {
-        DIAG(dg.k_entered[dg.kind]++; dg.k_blanes[dg.kind] += (unsigned long long)__popcll(__ballot(hit));)
-        pc += (uint32_t)sizeof(ProgBound);
-      } else {
-        DIAG(dg.n_skip++;)
-        if (!(kf & kRecFlag)) {
-          lens[level * kBlock + tid] = 0;
-          level++;
-        }
-        pc = R[1];
-      }
-      continue;
-    }
-    if (kind == kRecLeaf) {
+    if (kf & kRecIsLeaf) {
       // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
       const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
       const double im[12] = {REC_F64(0), REC_F64(1), REC_F64(2), REC_F64(3), REC_F64(4), REC_F64(5), REC_F64(6),
@@ -202,7 +189,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       level++;
       continue;
     }
-    if (kind == kRecOp) {
+    if (kf & kRecIsOp) {
       const uint32_t rule = R[1] & 3u;
       const uint32_t lenB = lens[(level - 1) * kBlock + tid], lenA = lens[(level - 2) * kBlock + tid];
       const uint32_t lb = lenB & 0x7FFFu, la = lenA & 0x7FFFu;
@@ -230,7 +217,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       pc += (uint32_t)sizeof(ProgSmall);
       continue;
     }
-    if (kind == kRecSkipEmpty) {
+    if (kf & kRecIsSkip) {
       // between the two operands of an intersection or a difference: the first one's list is empty for every
       // ray of the wave, so the operator's result is empty too; that empty list stays where it is and the
       // second operand and the operator are jumped over
@@ -238,7 +225,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       pc = __ballot(l != 0) ? pc + (uint32_t)sizeof(ProgSmall) : R[1];
       continue;
     }
-    if (kind == kRecTake) {
+    if (kf & kRecIsTake) {
       // a frontier child is complete: its list is the only one on the stack and, being an
       // operator's output, starts with an Entry and holds no sliver
       const uint32_t n = lens[tid] & 0x7FFFu;
