@@ -162,15 +162,16 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
                atomicAdd(&dg.leaf_dbg[leaf * 3 + 2], (unsigned long long)__popcll(be)); } })
       if (kf & kRecFlag) {
         // frontier leaf: no list, just a candidate for the nearest first Entry
-        if (entry) {
-          if (sliver) fl |= kFlRedo;
-          else if (!(best_m & kHitAny) || d0 < best || (d0 == best && leaf < (best_m & kLeafMask))) {
-            best = d0; best_m = leaf | ((uint32_t)ph.fA << kFaceShift) | kHitAny;
-          }
+        // (selects, not branches: as nested conditions this was five levels of lane-mask bookkeeping for eight
+        // instructions of work)
+        const bool nearer = !(best_m & kHitAny) | (d0 < best) | ((d0 == best) & (leaf < (best_m & kLeafMask)));
+        const bool upd = entry & !sliver & nearer;
+        fl |= (entry & sliver) ? kFlRedo : 0u;
+        best = upd ? d0 : best;
+        best_m = upd ? (leaf | ((uint32_t)ph.fA << kFaceShift) | kHitAny) : best_m;
 #if GMLRT_TSTOP
-          if ((best_m & kHitAny) && best <= t_stop) fl &= ~kFlActive;
+        fl &= (entry & ((best_m & kHitAny) != 0) & (best <= t_stop)) ? ~kFlActive : ~0u;
 #endif
-        }
         continue;
       }
       uint32_t n = 0;
