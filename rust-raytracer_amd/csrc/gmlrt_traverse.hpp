@@ -234,9 +234,12 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       if ((fl & kFlActive) && n) {
         const double d0 = evD[0];
         const uint32_t m0 = evM[0];
-        if (!(best_m & kHitAny) || d0 < best || (d0 == best && (m0 & kLeafMask) < (best_m & kLeafMask))) {
-          best = d0; best_m = m0 | kHitAny;
-        }
+        // (both loaded values are used right here, without a nested condition: a load still on its way when the
+        // loop goes round makes every record that follows wait for all memory traffic, event stores included,
+        // before it may touch that register)
+        const bool nearer = !(best_m & kHitAny) | (d0 < best) | ((d0 == best) & ((m0 & kLeafMask) < (best_m & kLeafMask)));
+        best = nearer ? d0 : best;
+        best_m = nearer ? (m0 | kHitAny) : best_m;
 #if GMLRT_TSTOP
         if (best <= t_stop) fl &= ~kFlActive;
 #endif
