@@ -38,7 +38,7 @@ __device__ inline PrimHit isect_sphere(V3 p, V3 d) {
   PrimHit r = {0, 0.0, 0.0, 0, 0};
   double s = vdot(vneg(p), d);
   double lsq = vdot(p, p);
-  if (s < 0.0 && lsq > 1.0) return r;
+  if ((s < 0.0) & (lsq > 1.0)) return r;
   double msq = lsq - s * s;
   if (msq > 1.0) return r;
   double q = sqrt(1.0 - msq);
@@ -141,7 +141,7 @@ __device__ inline PrimHit isect_cone(V3 p, V3 d) {
                        p.x * p.x + p.z * p.z - p.y * p.y, tc1, tc2))
     return r;
   const double cminy = p.y + tc1 * d.y, cmaxy = p.y + tc2 * d.y;
-  const bool k1 = 0.0 <= cminy && cminy <= 1.0, k2 = 0.0 <= cmaxy && cmaxy <= 1.0;
+  const bool k1 = (0.0 <= cminy) & (cminy <= 1.0), k2 = (0.0 <= cmaxy) & (cmaxy <= 1.0);
   double ta, tb;
   int fa = 0, fb = 0;
   if (k1 && k2) {

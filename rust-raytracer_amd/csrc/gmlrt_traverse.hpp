@@ -152,9 +152,9 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       pc += (uint32_t)sizeof(ProgLeaf);
       // a list that starts with Exit never raises its operand's counter above zero
       // (primitives.rs:254-293 start both counters at 0): same as no list at all
-      const bool entry = (fl & kFlActive) && (ph.bits & 1);
+      const bool entry = ((fl & kFlActive) != 0) & ((ph.bits & 1) != 0);
       const double d0 = scale * ph.tA, d1 = scale * ph.tB;
-      const bool sliver = (ph.bits & 2) && (d1 - d0 < 1e-10);
+      const bool sliver = ((ph.bits & 2) != 0) & (d1 - d0 < 1e-10);
       DIAG(dg.l_lanes += (unsigned long long)__popcll(__ballot((fl & kFlActive) != 0)); dg.l_hits += (unsigned long long)__popcll(__ballot(entry));
            if (!__ballot(entry)) dg.l_nohit++;
            { const unsigned long long be = __ballot(entry);
@@ -196,20 +196,14 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       const uint32_t lb = lenB & 0x7FFFu, la = lenA & 0x7FFFu;
       const bool slvA = lenA >> 15, slvB = lenB >> 15;
       const uint32_t a0 = sp - la - lb;
+      // One empty operand: the result is the other list as it stands (union; a difference's left operand), minus
+      // a lone sliver, or nothing.  Both non-empty: the sweep.  (Selects: the rule is the wave's, the lengths are
+      // the lanes'.)
+      const bool general = (la != 0) & (lb != 0);
+      const uint32_t keepA = slvA ? 0u : la, keepB = slvB ? 0u : lb;  // (B already sits at a0 when A is empty)
       uint32_t lout = 0;
-      bool general = false;
-      if (rule == GMLRT_UNION) {
-        if (lb == 0) lout = slvA ? 0 : la;
-        else if (la == 0) lout = slvB ? 0 : lb;  // B already sits at a0
-        else general = true;
-      } else if (rule == GMLRT_INTERSECT) {
-        general = la != 0 && lb != 0;
-      } else {
-        if (la != 0) {
-          if (lb == 0) lout = slvA ? 0 : la;
-          else general = true;
-        }
-      }
+      if (rule == GMLRT_UNION) lout = lb == 0 ? keepA : la == 0 ? keepB : 0u;
+      else if (rule != GMLRT_INTERSECT) lout = lb == 0 ? keepA : 0u;
       DIAG(if (__ballot(general)) dg.n_merge++;)
       if (general) lout = merge_any(R[1] & (3u | kOpSwapped), evD, evM, a0, la, lb);
       lens[(level - 2) * kBlock + tid] = (uint16_t)lout;
