@@ -337,6 +337,28 @@ def test_rarely_taken_paths(gmlrt, oracle, label, surf, scene):
     assert st.rays_shadow > 0 and st.rays_reflect > 0 and len(np.unique(img)) > 8
 
 
+@pytest.mark.parametrize("w,h,depth,lights", [(1, 1, 0, "[ l ]"), (1, 1, 5, "[ l ]"), (7, 9, 0, "[ ]"), (8, 8, 3, "[ ]"),
+                                              (9, 7, 2, "[ l l ]"), (64, 1, 4, "[ l ]"), (1, 64, 4, "[ l ]"), (65, 63, 1, "[ l ]")])
+def test_degenerate_sizes_depths_and_light_lists(gmlrt, oracle, w, h, depth, lights):
+    # one pixel, one row, one column, sizes just around the 8x8 pixel tiles; depth 0 (no bounce at all,
+    # raytracer.rs:96-107); an empty light array (ambient only) and the same light twice
+    text = ('{ /v /u /face 0.9 0.8 0.3 point 0.6 0.7 4.0 } sphere 0.0 0.0 3.0 translate '
+            '{ /v /u /face 0.3 0.5 0.9 point 0.8 0.4 2.0 } plane 0.0 -1.0 0.0 translate union /s '
+            '1.0 -1.0 1.0 point 0.9 0.9 0.9 point light /l '
+            '0.4 0.4 0.4 point %s s %d 90.0 %d %d "x.ppm" render' % (lights, depth, w, h))
+    call = gmlrt.Program(text=text).calls[0]
+    img, f64, st = gmlrt.render(call, want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=2)
+    assert img.shape == (h, w, 3) and (img == ref).all()
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert st.rays_primary == w * h
+    assert np.abs(f64 - ref64).max() <= 1e-9
+    if depth == 0:
+        assert st.rays_reflect == 0
+    if lights == "[ ]":
+        assert st.rays_shadow == 0
+
+
 def test_scene_of_the_independent_restatement(gmlrt, oracle):
     # the all-primitives scene that tests/independent_render.py pins the oracle with, on the GPU
     import independent_render as ind
