@@ -28,7 +28,7 @@ int fail(int code, const std::string& msg) {
 std::mutex g_mu;
 int g_n_gpus = 0;  // 0 = not initialised
 
-// validate_blob's verdict as a status: malformed, or well-formed but beyond the kernel's limits
+// what validate_blob found, as a status: malformed, or well-formed but beyond the kernel's limits
 int blob_status(const std::string& v) {
   if (v.empty()) return GMLRT_OK;
   return fail(v.rfind("too large:", 0) == 0 ? GMLRT_ERR_SCENE_TOO_LARGE : GMLRT_ERR_BAD_BLOB, v);
