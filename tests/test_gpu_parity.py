@@ -216,6 +216,18 @@ def test_full_size_rows_against_oracle(gmlrt, oracle):
     assert frac1 >= 0.999 and maxd <= 8
 
 
+def test_headline_frame_whole_against_oracle(gmlrt, oracle):
+    # every pixel of the 3840x2160 depth-5 chess frame and every ray count, against the oracle (about 15 s of its
+    # 16 threads): byte-identical, not merely within the tolerance
+    call = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0].with_overrides(3840, 2160, 5)
+    img, _, st = gmlrt.render(call)
+    ref, _, cnt = oracle.OracleProgram(path=os.path.join(SCENES, "chess.gml")).render(0, w=3840, h=2160, depth=5, threads=16)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print("4K whole frame: within1=%.6f max=%d differing=%d" % (frac1, maxd, ndiff), st.as_dict())
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
 @pytest.mark.parametrize("name,size,depth,step", [("large", (7680, 4320), 8, 240), ("fractal", (3840, 2160), 3, 360),
                                                   ("cone-fractal", (3840, 2160), 3, 360), ("house", (3840, 2160), 3, 180)])
 def test_other_configurations_full_size_rows_against_oracle(gmlrt, oracle, name, size, depth, step):
