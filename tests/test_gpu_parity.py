@@ -228,6 +228,20 @@ def test_headline_frame_whole_against_oracle(gmlrt, oracle):
     assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
 
 
+@pytest.mark.parametrize("name,size,depth", [("fractal", (3840, 2160), 3), ("cone-fractal", (3840, 2160), 3), ("large", (7680, 4320), 8),
+                                             ("house", (3840, 2160), 3), ("spotlight", (3840, 2160), 1), ("spheres", (3840, 2160), 3)])
+def test_other_configurations_whole_frames_against_oracle(gmlrt, oracle, name, size, depth):
+    # the other configuration scenes at their full sizes, every pixel and every ray count against the oracle
+    path = os.path.join(SCENES, name + ".gml")
+    call = gmlrt.Program(path=path).calls[0].with_overrides(size[0], size[1], depth)
+    img, _, st = gmlrt.render(call)
+    ref, _, cnt = oracle.OracleProgram(path=path).render(0, w=size[0], h=size[1], depth=depth, threads=16)
+    frac1, maxd, ndiff = image_diff(img, ref)
+    print("%s %dx%d whole frame: within1=%.6f max=%d differing=%d" % (name, size[0], size[1], frac1, maxd, ndiff))
+    assert ndiff == 0
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
 @pytest.mark.parametrize("name,size,depth,step", [("large", (7680, 4320), 8, 240), ("fractal", (3840, 2160), 3, 360),
                                                   ("cone-fractal", (3840, 2160), 3, 360), ("house", (3840, 2160), 3, 180)])
 def test_other_configurations_full_size_rows_against_oracle(gmlrt, oracle, name, size, depth, step):
