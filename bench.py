@@ -137,7 +137,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:  # noqa: BLE001
+                # RCCL unusable on this node (every rank sees the same failure at start-up): the path's only
+                # exchange is the host framebuffer, so the bookkeeping collectives can go over gloo
+                print("bench.py: nccl process group failed (%s); using gloo for the bookkeeping collectives" % e, file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
     if args.dry_run:
