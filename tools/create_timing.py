@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Time of gmlrt_scene_create (validation, derivation of the traversal and surface programs, uploads) for three scenes;
+with GMLRT_VERBOSE=1 the derivation alone is logged too.  Usage on the GPU box: python tools/create_timing.py"""
 import os, sys, time
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rust-raytracer_amd"))
 import gmlrt
 for name in ("chess", "fractal", "cone-fractal"):
