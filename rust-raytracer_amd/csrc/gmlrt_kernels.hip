@@ -1600,6 +1600,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   // (a call that must not allocate neither learns a hand-out order nor uses one: the tables are allocations)
   const bool no_order = no_order_env || no_alloc;
   const int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 4 ? s->order_state : s->order_state == 5 ? s->order_way : 0;
+  // The first launch with a geometry times its tiles and the host makes the other ways' tables from that: worth it
+  // only when a wave renders several tiles (a frame of fewer is never timed and stays with way 0).
+  const bool learning = s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave);
   A.tile_order = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_order : way == 3 ? (const uint32_t*)s->d_tile_order_rest : nullptr;
   A.batch_start = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img
                   : way == 3 ? (const uint32_t*)s->d_tile_batch_rest : nullptr;
@@ -1613,7 +1616,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.tail_lds_off = 0;
   {
     const bool tail_share = [] { const char* e = std::getenv("GMLRT_TAIL_SHARE"); return !(e && *e == '0'); }();  // tuning runs
-    const bool timing = s->order_state == 0 && !no_order && s->learn_order;
+    const bool timing = learning;
     if (tail_share && A.lds_ctx && s->slice_off[0] != 0 && lds_spare >= 16 && ((way == 0 && !timing) || way == 3)) {
       A.tail_lds_off = (uint32_t)lds_bytes;
       lds_bytes += 16;
@@ -1646,7 +1649,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
     while (st > 1 && gcd(st, n_tiles) != 1) st += 2;
     if (st < n_tiles) A.stride = (uint32_t)st;
   }
-  A.tile_cost = s->order_state == 0 && !no_order && s->learn_order ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
+  A.tile_cost = learning ? (uint32_t*)s->d_tile_cost : nullptr;  // only the learning launch times its tiles
   static const bool verbose_shared = std::getenv("GMLRT_VERBOSE") != nullptr;
   if (verbose_shared && way == 3 && s->order_state == 3) A.tile_cost = (uint32_t*)s->d_tile_cost;  // (what sharing did to the dear tiles, for the log)
 #ifdef GMLRT_DIAG
@@ -1753,7 +1756,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
                      "learnt order with %u shared tiles %.3f ms, learnt order with the rays of a block regrouped %.3f ms -> way %d\n",
                      s->order_ms[0], s->order_ms[1], s->order_ms[2], s->n_tiles_shared, s->order_ms[3], s->order_ms[4], s->order_way);
     }
-  } else if (s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave)) {
+  } else if (learning) {
     // first launch with this geometry: turn its per-tile costs into the order of the next ones
     // (worth it only when a wave renders several tiles)
     std::vector<uint32_t> cost(n_tiles), order(n_tiles);
