@@ -131,6 +131,25 @@ def test_blob_validation_rejects_corruption(gmlrt):
     assert b"" != L.gmlrt_last_error()
 
 
+def test_mutated_blobs_never_crash_the_host_side(gmlrt, tmp_path):
+    # The blob crosses the ABI from code the library does not control.  Valid blobs with random bit flips, byte and
+    # word overwrites, header damage and truncations go through what gmlrt_scene_create runs on the host (the
+    # validator; if it accepts, the derivation of the traversal and surface programs), built with AddressSanitizer
+    # and UBSan: any out-of-bounds access, overflow or crash fails the run.
+    import subprocess
+    csrc = os.path.join(ROOT, "rust-raytracer_amd", "csrc")
+    exe = str(tmp_path / "blob_fuzz")
+    subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-std=c++17", "-I", csrc,
+                    os.path.join(ROOT, "tests", "native", "blob_fuzz.cpp"), os.path.join(csrc, "gmlrt_program.cpp"),
+                    os.path.join(csrc, "gmlrt_scene.cpp"), os.path.join(csrc, "gml_front.cpp"), "-o", exe], check=True)
+    for name, n in (("chess", 400), ("spheres", 400), ("cone-fractal", 300)):
+        blob = tmp_path / (name + ".blob")
+        blob.write_bytes(bytes(gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].blob))
+        r = subprocess.run([exe, str(blob), str(n), "7"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "mutants" in r.stdout and "rejected" in r.stdout, r.stdout
+
+
 def _blob_with(n_lights=None, n_spheres=None):
     """A well-formed blob built by hand: a left-deep union of unit spheres (no bounds), constant surfaces."""
     n_leaves = n_spheres or 1
