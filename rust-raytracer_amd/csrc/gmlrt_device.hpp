@@ -120,6 +120,19 @@ struct DeviceScene {
   int dev_cus = 0;              // device facts, asked once: compute units, LDS per block and per unit,
   size_t dev_lds_block = 0, dev_lds_cu = 0;
   int dev_blocks_per_cu = 0;    // resident blocks per unit for this scene's LDS need
+  // Rendering level by level (hand-out way 5): bounce rays leave their lane for a device-wide queue and the next
+  // launch traces them regrouped.  Two ray queues used in turn, the keys and the sorted positions of the queued rays,
+  // one parked (c, sc, ks) record per pixel and bounce level, counters; the scene's box for the sort keys.
+  void* d_queue[2] = {nullptr, nullptr};
+  void* d_qkeys = nullptr;
+  void* d_qsorted = nullptr;
+  void* d_parked = nullptr;
+  void* d_qcnt = nullptr;
+  size_t queue_cap = 0;           // ray records each queue holds
+  size_t parked_records = 0;      // parked records allocated (pixels x levels)
+  double key_lo[3] = {0, 0, 0};   // sort keys: a grid over this box ...
+  double key_inv[3] = {0, 0, 0};  // ... with this many cells per unit on each axis
+  bool levels_refused = false;    // the buffers of way 5 could not be had for this handle's frames: do not ask again
   void* d_static_scratch = nullptr;  // this device's copy of the library's static scratch array (never freed)
   void* ev_start = nullptr;     // hipEvent_t pair used to time the kernel
   void* ev_stop = nullptr;

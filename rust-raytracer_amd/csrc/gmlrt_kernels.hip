@@ -59,6 +59,23 @@ constexpr uint32_t kTileBatchMax = 16;  // most tiles a batch of the table holds
 // Atomics on one address are served one after the other, device-wide (about 14 ns each, measured): the
 // batch counter is therefore split into several, far enough apart to be different memory channels.
 constexpr uint32_t kClaimCounters = 8, kClaimStride = 4096;
+// Level-by-level rendering: a queued ray is 8 words (origin, direction, pixel), a wave takes room for
+// kQueueChunk of them with one atomic (one per ray-pushing wave and round would be one per 4 ns of a 4K frame
+// on a single address, which serves one per 14 ns).
+constexpr uint32_t kRayWords = 8, kQueueChunk = 256, kKeyInvalid = 0xFFFFFFFFu;
+// Sort keys: the grid cell of the ray's origin (up to 8 x 8 cells over x and z, two layers in y) and its direction
+// (octant, and 4 x 4 bins inside the octant).
+constexpr uint32_t kKeyBitsMax = 3, kKeyDirBits = 7, kKeysMax = 1u << (2 * kKeyBitsMax + 1 + kKeyDirBits);
+// The queued rays are put in the order of their keys by a counting sort whose blocks each take kSortSegment
+// consecutive slots of the queue and count them in LDS first: a few keys hold most of the rays, and atomics on one
+// address are served one at a time, so the global counters see one addition per block and key, not one per wave.
+constexpr uint32_t kSortSegment = 4096;
+static_assert(kSortSegment % kQueueChunk == 0 && kSortSegment % 64 == 0, "segments are whole chunks and whole runs of 64 rays");
+constexpr uint32_t kMaxLevels = 1000;  // (level L claims its work from word L of each 4 KB claim counter)
+// Words of the level-by-level counter buffer: chunks handed out of the queue that feeds level l, rays in that level's
+// sorted table, the overflow flag, rays per key, where each key's run of the sorted table is filled next.
+constexpr size_t kQcChunks = 0, kQcSorted = kMaxLevels + 2, kQcOverflow = 2 * (kMaxLevels + 2), kQcHist = kQcOverflow + 60,
+                 kQcCursor = kQcHist + kKeysMax, kQcWords = kQcCursor + kKeysMax;
 // Layout of the per-scene counter buffer: the claim counters, 256 bytes of diagnostic counters, the ShadeArgs
 // record, one set of ray counts per block.
 constexpr size_t kOffDiag = (size_t)kClaimCounters * kClaimStride, kOffShadeArgs = kOffDiag + 256, kOffBlockCounts = kOffDiag + 1024;
@@ -123,6 +140,21 @@ struct KArgs {
   unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
   unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
+  // Rendering level by level (render_kernel<.., 3>): a launch traces the view rays of ONE bounce level and their
+  // shadow rays; a mirror bounce leaves its lane for a device-wide queue, which the next launch traces regrouped.
+  uint32_t level;                  // bounce level this launch starts at: 0 camera rays from the pixel tiles, else rays from q_in
+  uint32_t level_push;             // a bounce to this level is queued; one to a level below it stays in its lane
+  const uint64_t* q_in;            // this level's rays, kRayWords words each ...
+  const uint32_t* q_sorted;        // ... in the order of this table (positions into q_in) ...
+  const uint32_t* q_in_count;      // ... which holds this many entries
+  uint64_t* q_out;                 // the next level's rays, written in chunks of kQueueChunk records
+  uint32_t* q_out_keys;            // their sort keys (kKeyInvalid: a slot of a chunk that was never filled)
+  uint32_t* q_out_chunks;          // chunks handed out so far
+  uint32_t* q_overflow;            // set when the queue is full (never, with the capacity the host gives it)
+  uint32_t q_cap_chunks;
+  uint32_t key_bits;               // sort keys: cells per axis = 1 << key_bits ...
+  uint32_t key_mode;               // ... 0 no sorting (one key), 1 cell then direction octant, 2 octant then cell
+  double key_lo[3], key_inv[3];
 };
 
 // What the out-of-line per-ray code needs of the launch parameters.  It lives in
@@ -148,7 +180,8 @@ struct ShadeArgs {
   uint32_t* surf_error;        // set to 1 by a lane whose own surface program raised GMLRT_SOP_TRAP
   double* ctx;                 // context records of all waves (wave-major, then field, then lane)
   uint32_t vm_lds_off;         // byte offset of the block's register / hot-context region in its LDS
-  uint32_t pad2;
+  uint32_t parked_stride;      // level-by-level rendering: parked records per pixel (the depth of the call)
+  double* parked;              // ... and the records: 8 words for pixel p and level l at (p * parked_stride + l) * 8
 };
 
 static_assert(sizeof(ShadeArgs) <= kOffSurfError - kOffShadeArgs, "ShadeArgs outgrew its slot in the counter buffer");
@@ -541,14 +574,17 @@ __device__ inline int st_kind(uint32_t st) { return (int)(st & 3u); }
 // kLdsCtx: the block's LDS has room for the hot fields of the shading context (see gmlrt_shade.hpp);
 // a kernel per case, so that the loop below holds a single call site of after_traversal.
 // kMode: 0 the ordinary kernel; 1 the launch has tiles that the waves of a block render together; 2 the rays of a block are
-// regrouped before every traversal (both need the LDS context region).  Kernels of their own, so that the ordinary one
+// regrouped before every traversal (both need the LDS context region); 3 one launch per bounce level, a bounce ray
+// is queued for the next launch instead of staying in its lane.  Kernels of their own, so that the ordinary one
 // carries none of that.
 template <bool kLdsCtx, int kMode>
 __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes, const gmlrt_light* __restrict__ lights,
     const uint64_t* __restrict__ code, const uint64_t* __restrict__ consts, const gmlrt_bound* __restrict__ bounds,
     const uint8_t* __restrict__ prog, const ShadeArgs* __restrict__ shade_args, const KArgs A) {
-  constexpr bool kShared = kMode == 1, kRegroup = kMode == 2;
+  constexpr bool kShared = kMode == 1, kRegroup = kMode == 2, kLevels = kMode == 3;
+  // (waves that share rays get the owner's new camera rays only at a round that began with every lane idle)
+  static_assert(!kShared || GMLRT_REFILL_MIN == kWave, "sharing tiles among the waves of a block assumes whole-wave refills");
   extern __shared__ __align__(16) uint16_t lens[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -574,6 +610,20 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   uint32_t tile_left = 0;  // slots of it not handed out yet
   uint32_t batch_pos = 0, batch_end = 0;  // hand-outs claimed from the global counter and not started yet
   uint32_t claim_g = blockIdx.x % kClaimCounters, claim_tries = 0;  // counter in use, counters found empty
+  // Level-by-level rendering, levels above 0: the "tiles" are runs of 64 queued rays in sorted order, and how many
+  // there are is only known on the device.  q_pos .. q_end: room left in the wave's chunk of the outgoing queue.
+  [[maybe_unused]] uint32_t n_in = 0, q_pos = 0, q_end = 0;
+  uint32_t n_tiles_l = A.n_tiles, n_batches_l = A.n_batches;
+  [[maybe_unused]] uint32_t tile_batch_l = kTileBatch;
+  if constexpr (kLevels) {
+    if (A.level > 0) {
+      n_in = *A.q_in_count;
+      n_tiles_l = (n_in + 63u) / 64u;
+      // (few runs of rays: one per claim, so that no wave ends the launch with several of them in a row)
+      tile_batch_l = n_tiles_l > 16u * gridDim.x * (uint32_t)(kBlock / kWave) ? kTileBatch : 1u;
+      n_batches_l = (n_tiles_l + tile_batch_l - 1u) / tile_batch_l;
+    }
+  }
   // Tiles differ a lot in cost (sky: one traversal; a piece between mirrors: a dozen heavy ones) and
   // a wave follows its tile through every bounce, so the launch ends when the last expensive tile
   // does.  Each wave therefore notes how long its tiles took; the host sorts that into the hand-out
@@ -758,25 +808,38 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
           // counter g hands out batches g, g + 8, g + 16, ...; a wave starts with the counter of its block
           // (blocks go to the chip's eight dies in turn, so a die mostly keeps to one counter) and moves
           // on to the next when one has run out; all eight empty: nothing left
-          uint32_t b = A.n_batches;
+          uint32_t b = n_batches_l;
           while (claim_tries < kClaimCounters) {
             uint32_t k = 0;
+            if constexpr (kLevels) {
+              // once one counter has run out, a look before the atomic: the others have mostly run out too, and are
+              // passed by without one (at the end of a launch every wave finds all of them so, and atomics on one
+              // address are served one at a time; a stale value read here can only be too small, which costs the atomic
+              // it would have saved)
+              const uint32_t seen = claim_tries == 0 ? 0u : __hip_atomic_load((unsigned int*)((uint8_t*)A.next_batch + (size_t)claim_g * kClaimStride),
+                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (claim_tries != 0 && (uint64_t)seen * kClaimCounters + claim_g >= n_batches_l) {
+                claim_g = (claim_g + 1u) % kClaimCounters;
+                claim_tries++;
+                continue;
+              }
+            }
             if (lane == 0) k = atomicAdd((unsigned int*)((uint8_t*)A.next_batch + (size_t)claim_g * kClaimStride), 1u);
             k = (uint32_t)__shfl((int)k, 0);
             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             const uint64_t cand = (uint64_t)k * kClaimCounters + claim_g;
-            if (cand < A.n_batches) { b = (uint32_t)cand; break; }
+            if (cand < n_batches_l) { b = (uint32_t)cand; break; }
             claim_g = (claim_g + 1u) % kClaimCounters;
             claim_tries++;
           }
-          if (b >= A.n_batches) {
+          if (b >= n_batches_l) {
             none = true;
           } else if (A.batch_start) {
             batch_pos = A.batch_start[b];
             batch_end = A.batch_start[b + 1];
           } else {
-            batch_pos = b * kTileBatch;
-            batch_end = batch_pos + kTileBatch < A.n_tiles ? batch_pos + kTileBatch : A.n_tiles;
+            batch_pos = b * (kLevels ? tile_batch_l : kTileBatch);
+            batch_end = batch_pos + (kLevels ? tile_batch_l : kTileBatch) < n_tiles_l ? batch_pos + (kLevels ? tile_batch_l : kTileBatch) : n_tiles_l;
           }
         }
         const uint32_t t = none ? 0xFFFFFFFFu : batch_pos * 64u;
@@ -791,18 +854,35 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
         batch_pos++;
         tile_base = t;
         tile_left = 64u;
-        cur_tile = A.tile_order ? A.tile_order[t >> 6] : (uint32_t)(((uint64_t)(t >> 6) * A.stride) % A.n_tiles);
+        cur_tile = A.tile_order ? A.tile_order[t >> 6] : (uint32_t)(((uint64_t)(t >> 6) * A.stride) % n_tiles_l);
         tile_t0 = now;
         DIAG(w_tiles++;)
       }
       const uint32_t want = (uint32_t)__popcll(idle);
       const uint32_t take = want < tile_left ? want : tile_left;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-      if (st_kind(S.st) == kIdle && rank < take) GMLRT_CAMERA_RAY(cur_tile, (tile_base + rank) & 63u);
+      if (st_kind(S.st) == kIdle && rank < take) {
+        if (kLevels && A.level > 0) {
+          // the ray queued at this place of the sorted order (past the end of the table: the lane stays idle)
+          const uint32_t qi = cur_tile * 64u + ((tile_base + rank) & 63u);
+          if (qi < n_in) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2* __restrict__ r = (const d2*)(A.q_in + (size_t)A.q_sorted[qi] * kRayWords);
+            const d2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            S.o = {r0.x, r0.y, r1.x};
+            S.d = {r1.y, r2.x, r2.y};
+            S.pix = (uint32_t)__builtin_bit_cast(uint64_t, r3.x);
+            S.t_stop = -__builtin_inff();
+            S.st = kView | (A.level << 2);
+          }
+        } else {
+          GMLRT_CAMERA_RAY(cur_tile, (tile_base + rank) & 63u);
+        }
+      }
       tile_base += take;
       tile_left -= take;
       const unsigned long long idle_now = __ballot(st_kind(S.st) == kIdle);  // lanes that drew a padding slot are still idle
-      n_primary += (uint32_t)__popcll(idle & ~idle_now);
+      if (!kLevels || A.level == 0) n_primary += (uint32_t)__popcll(idle & ~idle_now);
       idle = idle_now;
     }
     if constexpr (kRegroup) {
@@ -813,7 +893,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     if constexpr (kShared) {
       if (tail && idle_at_top == ~0ull) {
         // the shared rays are all done (the same in all four waves): the owner has looked for another tile of its own
-        // above; what it found goes to the others, and if it found nothing everybody leaves
+        // above; what it found goes to the others, and if it found nothing everybody leaves.  The hand-out at the end
+        // of the round before used the same slots and no barrier lies between its reads and these writes: one here,
+        // which all four waves reach (they hold copies of the same ray states).
+        __syncthreads();
         GMLRT_HAND_OUT_RAYS();
         if (!__ballot(st_kind(S.st) != kIdle)) break;
       }
@@ -888,15 +971,74 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     uint32_t events = 0;  // its address goes to the callee: see the note at after_traversal
     if (st_kind(S.st) != kIdle && (!shared || owner)) {
       const uint32_t hm = h.any ? (h.meta | kHitAny) : 0u;
-      S = after_traversal<kLdsCtx, kRegroup>(S, h.dist, hm, shade_args, &events);
+      S = after_traversal<kLdsCtx, kRegroup, kLevels>(S, h.dist, hm, shade_args, &events);
+    }
+    if constexpr (kLevels) {
+      // ---- a mirror bounce leaves its lane: the ray goes to the queue of the next level, with the key the rays of
+      // that level are grouped by, and the lane is idle.  (What trace() keeps across the bounce has been parked per pixel.)
+      const bool mine = (events & kStReflect) != 0 && ((S.st >> 2) & 0x7FFu) == A.level_push;
+      const unsigned long long mb = __ballot(mine);
+      if (mb) {
+        const uint32_t n = (uint32_t)__popcll(mb), rank = (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+        const uint32_t room = q_end - q_pos, first = q_pos;
+        uint32_t second = 0;
+        bool full = false;
+        if (n > room) {
+          uint32_t c = 0;
+          if (lane == 0) c = atomicAdd(A.q_out_chunks, 1u);
+          c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+          if (c >= A.q_cap_chunks) {
+            // (cannot happen with the capacity the host gives the queue; the rays are dropped and the launch says so)
+            full = true;
+            if (lane == 0) *A.q_overflow = 1u;
+            q_pos = q_end = first + room;
+          } else {
+            second = c * kQueueChunk;
+            q_pos = second + (n - room);
+            q_end = second + kQueueChunk;
+          }
+        } else {
+          q_pos += n;
+        }
+        uint32_t key = 0;
+        if (mine && !(full && rank >= room)) {
+          const uint32_t at = rank < room ? first + rank : second + (rank - room);
+          typedef double d2 __attribute__((ext_vector_type(2)));
+          d2* __restrict__ r = (d2*)(A.q_out + (size_t)at * kRayWords);
+          r[0] = d2{S.o.x, S.o.y};
+          r[1] = d2{S.o.z, S.d.x};
+          r[2] = d2{S.d.y, S.d.z};
+          r[3] = d2{__builtin_bit_cast(double, (uint64_t)S.pix), 0.0};
+          if (A.key_mode) {
+            // grid cell of the origin (clamped into the scene's box) and bin of the direction
+            const int top = (1 << A.key_bits) - 1;
+            const double fx = (S.o.x - A.key_lo[0]) * A.key_inv[0], fy = (S.o.y - A.key_lo[1]) * A.key_inv[1], fz = (S.o.z - A.key_lo[2]) * A.key_inv[2];
+            const uint32_t cx = (uint32_t)(fx > 0.0 ? (fx < (double)top ? (int)fx : top) : 0);
+            const uint32_t cz = (uint32_t)(fz > 0.0 ? (fz < (double)top ? (int)fz : top) : 0);
+            const uint32_t cy = fy >= 1.0 ? 1u : 0u;
+            uint32_t cell = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < kKeyBitsMax; b++) cell |= (((cx >> b) & 1u) << (2 * b)) | (((cz >> b) & 1u) << (2 * b + 1));
+            cell |= cy << (2 * A.key_bits);
+            const float ax = __builtin_fabsf((float)S.d.x), ay = __builtin_fabsf((float)S.d.y), az = __builtin_fabsf((float)S.d.z);
+            const float inv = 4.0f / (ax + ay + az);
+            const uint32_t qa = (uint32_t)__builtin_fminf(ax * inv, 3.0f), qb = (uint32_t)__builtin_fminf(az * inv, 3.0f);
+            const uint32_t dir = ((S.d.x < 0.0 ? 1u : 0u) | (S.d.z < 0.0 ? 2u : 0u) | (S.d.y < 0.0 ? 4u : 0u)) << 4 | qa << 2 | qb;
+            key = A.key_mode == 1 ? (cell << kKeyDirBits) | dir : (dir << (2 * A.key_bits + 1)) | cell;
+          }
+          A.q_out_keys[at] = key;
+        }
+        if (mine) S.st = kIdle;
+      }
     }
     if constexpr (kShared) {
       if (shared) {
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[2] += n_ - ds_t; ds_t = n_; })
         GMLRT_HAND_OUT_RAYS();
         DIAGS({ const unsigned long long n_ = __builtin_readcyclecounter(); ds_phase[3] += n_ - ds_t; ds_t = n_; })
-        // (the next round's candidates go to fields 0 and 1, its rays are written after the barrier that
-        // follows them: nothing here is overwritten while a wave may still read it)
+        // (the next round's candidates go to fields 0 and 1, and its rays are written after the barrier that follows
+        // them, or, when the rays are all done and the owner hands out a new tile at the top of the loop, after the
+        // barrier placed there: nothing here is overwritten while a wave may still read it)
       }
     }
     n_shadow += (uint32_t)__popcll(__ballot((events & kStShadow) != 0));
@@ -906,6 +1048,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
   }
 
   if (A.tile_cost && cur_tile != 0xFFFFFFFFu && lane == 0) A.tile_cost[cur_tile] = (uint32_t)(wall_clock64() - tile_t0);
+  if constexpr (kLevels) {
+    // the slots of the wave's last chunk that no ray went to
+    for (uint32_t i = q_pos + (uint32_t)lane; i < q_end; i += (uint32_t)kWave) A.q_out_keys[i] = kKeyInvalid;
+  }
 
   // ---- ray counters of the waves, summed over the block (in the first bytes of the operand-stack lengths, each wave in the slots of
   // its own lanes: the other waves may still be tracing) and stored per block; the host adds the blocks
@@ -917,7 +1063,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     if (tid < 4) {
       unsigned long long sum = 0;
       for (int w = 0; w < kBlock / kWave; w++) sum += ((const uint32_t*)lens)[w * (kWave / 2) + tid];
-      A.block_counts[(size_t)blockIdx.x * 4 + tid] = sum;
+      // (level by level: the launches of a frame add up; the host cleared the counts before the first)
+      if constexpr (kLevels) A.block_counts[(size_t)blockIdx.x * 4 + tid] += sum;
+      else A.block_counts[(size_t)blockIdx.x * 4 + tid] = sum;
     }
   }
   DIAGS(if (lane == 0) for (int q = 0; q < 4; q++) atomicAdd(&A.diag[wib * 4 + q], ds_phase[q]);)
@@ -936,6 +1084,76 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          for (int q = 0; q < 2; q++) atomicAdd(&A.diag[30 + q], dg.k_active[q]);
          )
   }
+}
+
+// ---- level-by-level rendering: between two launches the queued rays are put in the order of their keys, a counting
+// sort of their positions (the ray records stay where they were written) in three steps: rays per key; where each
+// key's run starts; every position to its place.  Slots of chunks that were never filled drop out.
+// Steps 1 and 3: block g takes slots [g * kSortSegment, (g + 1) * kSortSegment) of the queue and counts them per key
+// in LDS (which also numbers the rays of a key within the block); kPlace = false adds the counts to the global
+// histogram, kPlace = true takes the block's share of every key's run and writes the positions there.
+template <bool kPlace>
+__global__ __launch_bounds__(kBlock) void levels_sort_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_chunks,
+                                                             uint32_t cap_chunks, uint32_t n_keys, uint32_t* __restrict__ counters,
+                                                             uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t bins[kKeysMax];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunks = *n_chunks < cap_chunks ? *n_chunks : cap_chunks;
+  const uint32_t n_flat = chunks * kQueueChunk;
+  constexpr uint32_t kPer = kSortSegment / kBlock;
+  for (uint32_t seg = blockIdx.x; seg * kSortSegment < n_flat; seg += gridDim.x) {
+    const uint32_t base = seg * kSortSegment;
+    for (uint32_t k = tid; k < n_keys; k += kBlock) bins[k] = 0;
+    __syncthreads();
+    uint32_t key[kPer], rank[kPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) {
+      const uint32_t i = base + j * kBlock + tid;
+      key[j] = i < n_flat ? keys[i] : kKeyInvalid;
+      rank[j] = key[j] != kKeyInvalid ? atomicAdd(&bins[key[j]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < n_keys; k += kBlock) {
+      const uint32_t c = bins[k];
+      if (kPlace) bins[k] = c ? atomicAdd(counters + k, c) : 0u;
+      else if (c) atomicAdd(counters + k, c);
+    }
+    __syncthreads();
+    if constexpr (kPlace) {
+#pragma unroll
+      for (uint32_t j = 0; j < kPer; j++)
+        if (key[j] != kKeyInvalid) sorted[bins[key[j]] + rank[j]] = base + j * kBlock + tid;
+      __syncthreads();
+    }
+  }
+}
+// Step 2, one block: where each key's run starts in the sorted table (exclusive prefix sums of the histogram, which
+// is cleared for the next launch's rays), and how many rays there are.
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void levels_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                                    uint32_t n_keys, uint32_t* __restrict__ n_sorted) {
+  __shared__ uint32_t part[kScanThreads];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (n_keys + kScanThreads - 1) / kScanThreads;
+  const uint32_t k0 = tid * per < n_keys ? tid * per : n_keys, k1 = k0 + per < n_keys ? k0 + per : n_keys;
+  uint32_t sum = 0;
+  for (uint32_t k = k0; k < k1; k++) sum += hist[k];
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t step = 1; step < (uint32_t)kScanThreads; step <<= 1) {
+    const uint32_t add = tid >= step ? part[tid - step] : 0u;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;  // rays of all keys before k0
+  for (uint32_t k = k0; k < k1; k++) {
+    const uint32_t c = hist[k];
+    cursor[k] = run;
+    hist[k] = 0;
+    run += c;
+  }
+  if (tid == kScanThreads - 1) *n_sorted = part[tid];
 }
 
 // Scratch of the entry point that allocates nothing (dev_render with no_alloc): claim counters, launch
@@ -1154,6 +1372,12 @@ void free_workspace(DeviceScene* s) {
   (void)hipFree(s->d_tile_batch_rest);
   (void)hipFree(s->d_tiles_shared);
   (void)hipFree(s->d_xchg);
+  (void)hipFree(s->d_queue[0]);
+  (void)hipFree(s->d_queue[1]);
+  (void)hipFree(s->d_qkeys);
+  (void)hipFree(s->d_qsorted);
+  (void)hipFree(s->d_parked);
+  (void)hipFree(s->d_qcnt);
   if (s->h_staging) (void)hipHostFree(s->h_staging);
   if (s->ev_start) (void)hipEventDestroy((hipEvent_t)s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy((hipEvent_t)s->ev_stop);
@@ -1314,6 +1538,31 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
   out->device = device;
   out->blob_bytes = bytes;
   std::memcpy(&out->hdr, blob, sizeof(out->hdr));
+  out->levels_refused = false;
+  {
+    // The box the sort keys of queued rays are laid over: the bounded primitives' own boxes, taken to world space
+    // (a half-space has none; a scene of nothing else gets a box around the origin).  Only the grouping of the rays
+    // depends on it, never a result.
+    const gmlrt_blob_header& H = out->hdr;
+    const gmlrt_leaf* L = (const gmlrt_leaf*)((const uint8_t*)blob + H.off_leaves);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < H.n_leaves; i++) {
+      if (L[i].type == GMLRT_PLANE) continue;
+      const double olo[3] = {L[i].type == GMLRT_CUBE ? 0.0 : -1.0, L[i].type == GMLRT_SPHERE ? -1.0 : 0.0, L[i].type == GMLRT_CUBE ? 0.0 : -1.0};
+      for (int c = 0; c < 8; c++) {
+        const double q[3] = {(c & 1) ? 1.0 : olo[0], (c & 2) ? 1.0 : olo[1], (c & 4) ? 1.0 : olo[2]};
+        for (int a = 0; a < 3; a++) {
+          const double v = L[i].m[a * 4] * q[0] + L[i].m[a * 4 + 1] * q[1] + L[i].m[a * 4 + 2] * q[2] + L[i].m[a * 4 + 3];
+          if (v == v) { lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        }
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      if (!(hi[a] > lo[a]) || !(hi[a] - lo[a] < 1e30)) { lo[a] = -10.0; hi[a] = 10.0; }
+      out->key_lo[a] = lo[a];
+      out->key_inv[a] = 1.0 / (hi[a] - lo[a]);  // cells per unit for ONE cell over the box; the launch scales it
+    }
+  }
   HIP_TRY(hipMalloc(&out->d_blob, bytes));
   HIP_TRY(hipMemcpy(out->d_blob, blob, bytes, hipMemcpyHostToDevice));
   {
@@ -1403,6 +1652,8 @@ void dev_scene_destroy(DeviceScene* s) {
   spare.d_tile_cost = s->d_tile_cost; spare.d_tile_order = s->d_tile_order; spare.d_tile_batch = s->d_tile_batch; spare.d_tile_batch_img = s->d_tile_batch_img;
   spare.d_tile_order_rest = s->d_tile_order_rest; spare.d_tile_batch_rest = s->d_tile_batch_rest; spare.d_tiles_shared = s->d_tiles_shared;
   spare.d_xchg = s->d_xchg; spare.xchg_blocks = s->xchg_blocks;
+  spare.d_queue[0] = s->d_queue[0]; spare.d_queue[1] = s->d_queue[1]; spare.d_qkeys = s->d_qkeys; spare.d_qsorted = s->d_qsorted;
+  spare.d_parked = s->d_parked; spare.d_qcnt = s->d_qcnt; spare.queue_cap = s->queue_cap; spare.parked_records = s->parked_records;
   spare.h_staging = s->h_staging; spare.tiles_alloc = s->tiles_alloc;
   spare.ev_start = s->ev_start; spare.ev_stop = s->ev_stop;
   bool kept = false;
@@ -1599,10 +1850,57 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   static const bool no_order_env = std::getenv("GMLRT_NO_TILE_ORDER") != nullptr;  // tuning runs
   // (a call that must not allocate neither learns a hand-out order nor uses one: the tables are allocations)
   const bool no_order = no_order_env || no_alloc;
-  const int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 4 ? s->order_state : s->order_state == 5 ? s->order_way : 0;
+  int way = !s->order_valid || no_order ? 0 : s->order_state >= 1 && s->order_state <= 4 ? s->order_state : s->order_state == 5 ? s->order_way : 0;
+  // ---- level by level (way 5): one launch per bounce level, bounce rays queued and regrouped in between.  It needs
+  // no tile costs, so a frame rendered once runs as fast as a repeated one.  Buffers: two ray queues (a level can hold
+  // one ray per pixel, plus the chunks the waves have not filled), keys and sorted positions, one parked record per
+  // pixel and level.  A frame that can have no bounce, a call that must not allocate, or buffers beyond the limit
+  // (GMLRT_LEVELS_MAX_GB, default 24) stay with the one-launch kernel.
+  bool levels = false;
+  size_t q_cap_chunks = 0;
+  const size_t n_pix = (size_t)rows * (size_t)p.width;
+  {
+    const char* e = std::getenv("GMLRT_LEVELS");  // read at every call (tests switch between the two kernels)
+    const bool wanted = e && *e == '1';
+    if (wanted && !no_alloc && p.depth > 0 && p.depth <= (int64_t)kMaxLevels && !s->levels_refused) {
+      const size_t waves = (size_t)grid * (kBlock / kWave);
+      q_cap_chunks = (n_pix + kQueueChunk - 1) / kQueueChunk + waves + 1;
+      const size_t cap = q_cap_chunks * kQueueChunk;
+      const size_t parked = n_pix * (size_t)p.depth;
+      static const double max_gb = [] { const char* m = std::getenv("GMLRT_LEVELS_MAX_GB"); return m ? std::atof(m) : 24.0; }();
+      const double bytes = (double)cap * (2.0 * kRayWords * 8 + 8) + (double)parked * 64.0;
+      if (cap < 0xFFFF0000ull && bytes <= max_gb * 1073741824.0) {
+        levels = true;
+        if (cap > s->queue_cap) {
+          for (int q = 0; q < 2; q++) { (void)hipFree(s->d_queue[q]); s->d_queue[q] = nullptr; }
+          (void)hipFree(s->d_qkeys);
+          (void)hipFree(s->d_qsorted);
+          s->d_qkeys = s->d_qsorted = nullptr;
+          s->queue_cap = 0;
+          bool ok = true;
+          for (int q = 0; q < 2; q++) ok = ok && hipMalloc(&s->d_queue[q], cap * kRayWords * sizeof(uint64_t)) == hipSuccess;
+          ok = ok && hipMalloc(&s->d_qkeys, cap * sizeof(uint32_t)) == hipSuccess;
+          ok = ok && hipMalloc(&s->d_qsorted, cap * sizeof(uint32_t)) == hipSuccess;
+          if (ok) s->queue_cap = cap; else levels = false;
+        }
+        if (levels && parked > s->parked_records) {
+          (void)hipFree(s->d_parked);
+          s->d_parked = nullptr;
+          s->parked_records = 0;
+          if (hipMalloc(&s->d_parked, parked * 8 * sizeof(double)) == hipSuccess) s->parked_records = parked; else levels = false;
+        }
+        if (levels && !s->d_qcnt && hipMalloc(&s->d_qcnt, kQcWords * sizeof(uint32_t)) != hipSuccess) { s->d_qcnt = nullptr; levels = false; }
+        if (!levels) {
+          (void)hipGetLastError();  // out of memory: not an error of this call, the one-launch kernel renders the frame
+          s->levels_refused = true;
+        }
+      }
+    }
+  }
+  if (levels) way = 5;
   // The first launch with a geometry times its tiles and the host makes the other ways' tables from that: worth it
   // only when a wave renders several tiles (a frame of fewer is never timed and stays with way 0).
-  const bool learning = s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave);
+  const bool learning = !levels && s->order_state == 0 && !no_order && s->learn_order && n_tiles >= 2 * (size_t)grid * (kBlock / kWave);
   A.tile_order = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_order : way == 3 ? (const uint32_t*)s->d_tile_order_rest : nullptr;
   A.batch_start = way == 1 || way == 4 ? (const uint32_t*)s->d_tile_batch : way == 2 ? (const uint32_t*)s->d_tile_batch_img
                   : way == 3 ? (const uint32_t*)s->d_tile_batch_rest : nullptr;
@@ -1687,6 +1985,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
   SA.ctx = A.ctx;
   SA.vm_lds_off = A.vm_lds_off;
+  SA.parked = levels ? (double*)s->d_parked : nullptr;
+  SA.parked_stride = (uint32_t)p.depth;
 #ifdef GMLRT_DIAG
   unsigned long long* d_diag_waves = nullptr;
   HIP_TRY(hipMalloc(&d_diag_waves, lanes / kWave * kDiagWaveSlots * sizeof(unsigned long long)));
@@ -1698,6 +1998,74 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   std::memcpy(s->h_staging, &SA, sizeof(SA));
   HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, kOffBlockCounts - kOffShadeArgs, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
+  if (levels) {
+    uint32_t* qc = (uint32_t*)s->d_qcnt;
+    // (tuning runs and tests; read at every call)
+    const uint32_t key_mode = [] { const char* e = std::getenv("GMLRT_LEVELS_SORT"); const int v = e ? std::atoi(e) : 1; return (uint32_t)(v < 0 || v > 2 ? 1 : v); }();
+    const uint32_t key_bits = [] { const char* e = std::getenv("GMLRT_LEVELS_KEY_BITS"); const int v = e ? std::atoi(e) : (int)kKeyBitsMax; return (uint32_t)(v < 1 ? 1 : v > (int)kKeyBitsMax ? (int)kKeyBitsMax : v); }();
+    const uint32_t n_keys = key_mode ? 1u << (2 * key_bits + 1 + kKeyDirBits) : 1u;
+    A.key_mode = key_mode;
+    A.key_bits = key_bits;
+    for (int a = 0; a < 3; a++) { A.key_lo[a] = s->key_lo[a]; A.key_inv[a] = s->key_inv[a] * (a == 1 ? 2.0 : (double)(1u << key_bits)); }
+    A.q_sorted = (const uint32_t*)s->d_qsorted;
+    A.q_out_keys = (uint32_t*)s->d_qkeys;
+    A.q_overflow = qc + kQcOverflow;
+    A.q_cap_chunks = (uint32_t)q_cap_chunks;
+    A.n_batches = (uint32_t)((n_tiles + kTileBatch - 1) / kTileBatch);
+    // (the launches of a frame add their ray counts up, and each level claims its work from counters of its own)
+    HIP_TRY(hipMemsetAsync(qc, 0, (kQcHist + n_keys) * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_counters + kOffBlockCounts, 0, (size_t)grid * 4 * sizeof(unsigned long long), stream));
+    const unsigned sort_blocks = (unsigned)std::min<size_t>((q_cap_chunks * kQueueChunk + kSortSegment - 1) / kSortSegment, (size_t)prop.multiProcessorCount * 8);
+    // The launches: starts[g] is the level launch g begins at; a bounce to a level below the next launch's start stays
+    // in its lane (GMLRT_LEVEL_CUTS: the starts after 0, a comma-separated list; default 2, 3, ... depth).
+    std::vector<int64_t> starts = {0};
+    {
+      const char* e = std::getenv("GMLRT_LEVEL_CUTS");  // tuning runs
+      if (e && *e) {
+        for (const char* q = e; *q;) {
+          const long v = std::strtol(q, const_cast<char**>(&q), 10);
+          if (v > starts.back() && v <= p.depth) starts.push_back(v);
+          while (*q == ',') q++;
+          if (!(*q >= '0' && *q <= '9')) break;
+        }
+      } else {
+        // (the first bounce stays in its lane: the 64 rays of a tile that have just left neighbouring points of one
+        // surface are a better group than anything the sort makes of them; chess 4K depth 5: 3.6 ms against 4.0)
+        for (int64_t L = 2; L <= p.depth; L++) starts.push_back(L);
+      }
+    }
+    for (size_t g = 0; g < starts.size(); g++) {
+      const int64_t L = starts[g], L_next = g + 1 < starts.size() ? starts[g + 1] : p.depth + 1;
+      if (L > 0) {
+        if ((g & 7) == 0) {
+          // a deep `depth`: every eighth launch the host looks whether any ray is left (the frames of the
+          // configurations never get here)
+          HIP_TRY(hipMemcpyAsync(s->h_staging, qc + kQcChunks + L, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipStreamSynchronize(stream));
+          if (*(const uint32_t*)s->h_staging == 0) break;
+        }
+        hipLaunchKernelGGL((levels_sort_kernel<false>), dim3(sort_blocks), dim3(kBlock), 0, stream, (const uint32_t*)s->d_qkeys,
+                           (const uint32_t*)(qc + kQcChunks + L), (uint32_t)q_cap_chunks, n_keys, qc + kQcHist, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, qc + kQcHist, qc + kQcCursor, n_keys, qc + kQcSorted + L);
+        hipLaunchKernelGGL((levels_sort_kernel<true>), dim3(sort_blocks), dim3(kBlock), 0, stream, (const uint32_t*)s->d_qkeys,
+                           (const uint32_t*)(qc + kQcChunks + L), (uint32_t)q_cap_chunks, n_keys, qc + kQcCursor, (uint32_t*)s->d_qsorted);
+      }
+      A.level = (uint32_t)L;
+      A.level_push = (uint32_t)L_next;
+      A.q_in = (const uint64_t*)s->d_queue[g & 1];
+      A.q_in_count = qc + kQcSorted + L;
+      A.q_out = (uint64_t*)s->d_queue[(g + 1) & 1];
+      A.q_out_chunks = qc + kQcChunks + L_next;
+      A.next_batch = (unsigned int*)d_counters + L;  // the claim counters of the launch: word L of each counter's 4 KB
+      if (A.lds_ctx)
+        hipLaunchKernelGGL((render_kernel<true, 3>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                           d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
+      else
+        hipLaunchKernelGGL((render_kernel<false, 3>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
+                           d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
+      HIP_TRY(hipGetLastError());
+    }
+  } else
   if (A.lds_ctx && A.xchg)
     hipLaunchKernelGGL((render_kernel<true, 2>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, stream, d_leaves, d_nodes, d_lights,
                        d_code, d_consts, d_bounds, (const uint8_t*)s->d_prog, (const ShadeArgs*)(d_counters + kOffShadeArgs), A);
@@ -1716,7 +2084,10 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   const unsigned long long* per_block = (const unsigned long long*)((uint8_t*)s->h_staging + 1024);
   HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 8, d_counters + kOffSurfError, 8 + (size_t)grid * 4 * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, stream));
+  *(uint32_t*)((uint8_t*)s->h_staging + 1024 - 16) = 0;
+  if (levels) HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 16, (uint32_t*)s->d_qcnt + kQcOverflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  if (*(const uint32_t*)((const uint8_t*)s->h_staging + 1024 - 16) != 0) return "ray queue overflow";
   unsigned long long counts[4] = {0, 0, 0, 0};
   for (size_t b = 0; b < (size_t)grid; b++)
     for (int k = 0; k < 4; k++) counts[k] += per_block[b * 4 + k];

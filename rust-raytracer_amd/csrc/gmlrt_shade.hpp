@@ -45,7 +45,11 @@ __device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD
 // kSlot: rays change lanes between traversals (the kernel that regroups the rays of a block), so the context belongs to
 // the ray, not to the lane: bits 31..24 of S.st name the block's context slot the ray owns, and that slot takes the place
 // of the thread's position in every address below.  The bits are handed back unchanged.
-template <bool kLds, bool kSlot>
+//
+// kLevels: the frame is rendered level by level; a bounce ray leaves this lane (the caller queues it for the next
+// launch), so what trace() keeps across its recursive call, (c, sc, ks), is parked per PIXEL and level, where the
+// lane that ends the pixel's chain of bounces, in whatever launch, finds it.
+template <bool kLds, bool kSlot, bool kLevels = false>
 __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
                                                   const ShadeArgs* __restrict__ SA_v, uint32_t* __restrict__ events_out) {
   const ShadeArgs* __restrict__ SA = const_space(wave_uniform(SA_v));
@@ -229,10 +233,15 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
         const V3 raydir = cold_get3(ctx, C_RDIR);
         const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
         // park (c, sc, ks) until the bounce below returns
-        const int f = kCtxFixed + level * kCtxPerLevel;
-        cold_set3(ctx, f, c);
-        cold_set3(ctx, f + 3, sc);
-        COLD(f + 6) = ks;
+        if constexpr (kLevels) {
+          double* __restrict__ pk = global_space(wave_uniform(SA->parked)) + ((size_t)S.pix * SA->parked_stride + (uint32_t)level) * 8;
+          pk[0] = c.x; pk[1] = c.y; pk[2] = c.z; pk[3] = sc.x; pk[4] = sc.y; pk[5] = sc.z; pk[6] = ks;
+        } else {
+          const int f = kCtxFixed + level * kCtxPerLevel;
+          cold_set3(ctx, f, c);
+          cold_set3(ctx, f + 3, sc);
+          COLD(f + 6) = ks;
+        }
         S.o = vadd(pos, vmul(refl, 1e-7));
         S.d = refl;
         S.t_stop = -__builtin_inff();
@@ -250,10 +259,19 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
   if (finish) {
     // unwind the parked levels: c + (rc * sc) * ks, raytracer.rs:103-104
     for (int lv = level - 1; lv >= 0; lv--) {
-      const int f = kCtxFixed + lv * kCtxPerLevel;
-      const V3 c = cold_get3(ctx, f);
-      const V3 psc = cold_get3(ctx, f + 3);
-      const double pks = COLD(f + 6);
+      V3 c, psc;
+      double pks;
+      if constexpr (kLevels) {
+        const double* __restrict__ pk = global_space(wave_uniform(SA->parked)) + ((size_t)S.pix * SA->parked_stride + (uint32_t)lv) * 8;
+        c = {pk[0], pk[1], pk[2]};
+        psc = {pk[3], pk[4], pk[5]};
+        pks = pk[6];
+      } else {
+        const int f = kCtxFixed + lv * kCtxPerLevel;
+        c = cold_get3(ctx, f);
+        psc = cold_get3(ctx, f + 3);
+        pks = COLD(f + 6);
+      }
       C = vadd(c, vmul(vcmul(C, psc), pks));
     }
     const size_t oidx = (size_t)S.pix * 3;

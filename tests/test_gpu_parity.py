@@ -52,6 +52,15 @@ def test_chess_depth5_reduced_size(gmlrt, oracle):
     assert st.rays_reflect > cnt["primary"] * 0.5  # depth matters in this scene: every surface is a mirror
 
 
+def _oracle_rows(oracle, name, size, depth, n_rows=9):
+    """A spread of full-width rows of the frame from the oracle: (row numbers, their pixels)."""
+    step = max(1, size[1] // n_rows)
+    y0 = step // 2
+    ref, _, _ = oracle.OracleProgram(path=os.path.join(SCENES, name + ".gml")).render(
+        0, w=size[0], h=size[1], depth=depth, y0=y0, y1=size[1], ystep=step, threads=16)
+    return list(range(y0, size[1], step)), ref
+
+
 def test_row_partitions_reassemble(gmlrt):
     # interleaved row tiles rendered separately give the same bytes as one full render
     prog = gmlrt.Program(path=os.path.join(SCENES, "chess.gml"))
@@ -108,7 +117,7 @@ def test_every_way_of_handing_out_tiles_gives_the_same_image(gmlrt, name, size, 
     ("fractal", (3840, 2160), 3, 1, 0, "0.2"),   # a frontier of thousands of children, dealt round-robin
     ("cone-fractal", (1920, 1080), 4, 1, 0, "0.1"),
 ])
-def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, name, size, depth, nparts, part, share):
+def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, oracle, name, size, depth, nparts, part, share):
     # Way 3 of handing out tiles: the dearest ones are rendered by four waves together, each walking a quarter of
     # the scene's frontier for the same 64 rays (launch 4 of a handle tries it, later launches may keep it).  Same
     # bytes and same ray counts as the launch that knew no costs, and as the rows of the one-shot render.
@@ -117,6 +126,10 @@ def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, name, s
     full, _, _ = gmlrt.render(call)
     h, w = size[1], size[0]
     rows = gmlrt.part_row_index(h, 8, part, nparts)
+    # the oracle's word on a spread of this partition's rows (the frames below are compared with `full`, the
+    # one-launch kernel's image: that image itself is pinned here)
+    o_rows, o_ref = _oracle_rows(oracle, name, size, depth)
+    assert (full[o_rows] == o_ref).all()
     p = gmlrt.Params()
     ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
     p.tile_rows, p.part, p.nparts = 8, part, nparts
@@ -146,13 +159,14 @@ def test_tiles_shared_by_the_waves_of_a_block_give_the_same_image(gmlrt, name, s
 
 @pytest.mark.parametrize("name,size,depth,mode", [("chess", (1921, 1081), 5, "0"), ("chess", (1920, 1080), 3, "5"),
                                                   ("fractal", (1920, 1080), 3, "2"), ("spotlight", (1920, 1080), 4, "1")])
-def test_regrouping_the_rays_of_a_block_gives_the_same_image(gmlrt, name, size, depth, mode):
+def test_regrouping_the_rays_of_a_block_gives_the_same_image(gmlrt, oracle, name, size, depth, mode):
     # The kernel that sorts a block's 256 rays into its four waves before every traversal (a ray changes lanes and
     # takes its state and the number of its context slot along) is tried by a handle only on request; every way of
     # sorting and both ways of taking new tiles must give the bytes and the ray counts of the ordinary kernel.
     import torch
     call = gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].with_overrides(size[0], size[1], depth)
     ref, _, st_ref = gmlrt.render(call)
+    o_rows, o_ref = _oracle_rows(oracle, name, size, depth)
     os.environ["GMLRT_REGROUP_RAYS"] = "1"
     os.environ["GMLRT_REGROUP_MODE"] = mode
     try:
@@ -163,7 +177,9 @@ def test_regrouping_the_rays_of_a_block_gives_the_same_image(gmlrt, name, size, 
             buf.fill_(0x5A)
             st = scene.render_into(call.params, buf.data_ptr())
             ways.append(st.handout_way)
-            assert (buf.cpu().numpy() == ref).all(), (name, launch)
+            img = buf.cpu().numpy()
+            assert (img == ref).all(), (name, launch)
+            assert (img[o_rows] == o_ref).all(), (name, launch)  # and the oracle's rows, at these ragged sizes too
             assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits) == \
                    (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits), (name, launch)
         scene.close()
@@ -171,6 +187,72 @@ def test_regrouping_the_rays_of_a_block_gives_the_same_image(gmlrt, name, size, 
     finally:
         for k in ("GMLRT_REGROUP_RAYS", "GMLRT_REGROUP_MODE"):
             os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("name,size,depth,cuts,sort", [
+    ("chess", (481, 271), 5, None, None),         # ragged tiles, every piece, depth 5
+    ("chess", (480, 270), 5, "1,2,3,4,5", "2"),   # a launch per level, the other key order
+    ("chess", (480, 270), 5, "3", "0"),           # two launches, no sorting (queue order)
+    ("fractal", (300, 200), 3, None, None),
+    ("cone-fractal", (301, 199), 3, "1,3", None),
+    ("house", (400, 240), 3, None, None),         # no lights: view rays and bounces only
+    ("spheres", (640, 480), 3, None, None),
+    ("spotlight", (320, 240), 1, None, None),     # a bare primitive as root, matte: the queue stays empty
+])
+def test_level_by_level_rendering_matches_oracle(gmlrt, oracle, monkeypatch, name, size, depth, cuts, sort):
+    # GMLRT_LEVELS=1: one launch per bounce level, bounce rays queued in device memory with what trace() keeps across
+    # the bounce parked per pixel, sorted by origin cell and direction, traced regrouped by the next launch.  Every
+    # pixel (quantised and f64) and every ray count against the oracle, through the host entry point.
+    monkeypatch.setenv("GMLRT_LEVELS", "1")
+    if cuts:
+        monkeypatch.setenv("GMLRT_LEVEL_CUTS", cuts)
+    if sort:
+        monkeypatch.setenv("GMLRT_LEVELS_SORT", sort)
+    img, f64, st, ref, ref64, cnt = _both(gmlrt, oracle, name, size[0], size[1], depth)
+    assert st.handout_way == (5 if depth > 0 else 0)
+    assert (img == ref).all()
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    both = np.isfinite(f64) & np.isfinite(ref64)
+    assert (np.isfinite(f64) == np.isfinite(ref64)).all()
+    assert np.abs(f64[both] - ref64[both]).max() <= 1e-9
+
+
+def test_level_by_level_rendering_of_row_partitions_and_full_frames(gmlrt, oracle, monkeypatch):
+    # the same path through the device entry point: row partitions reassembled, a handle used for several frames of
+    # different sizes (its queues grow), and the headline frame whole against the one-launch kernel's image, which
+    # test_headline_frame_whole_against_oracle pins to the oracle
+    import torch
+    call = gmlrt.Program(path=os.path.join(SCENES, "chess.gml")).calls[0].with_overrides(3840, 2160, 5)
+    monkeypatch.setenv("GMLRT_LEVELS", "0")
+    ref, _, st_ref = gmlrt.render(call)
+    o_rows, o_ref = _oracle_rows(oracle, "chess", (3840, 2160), 5, n_rows=6)
+    assert (ref[o_rows] == o_ref).all()
+    monkeypatch.setenv("GMLRT_LEVELS", "1")
+    scene = gmlrt.DeviceScene(call.blob, 0)
+    small = call.with_overrides(333, 222, 4)
+    buf = torch.empty((222, 333, 3), dtype=torch.uint8, device="cuda:0")
+    st = scene.render_into(small.params, buf.data_ptr())
+    monkeypatch.setenv("GMLRT_LEVELS", "0")
+    small_ref, _, small_st = gmlrt.render(small)
+    monkeypatch.setenv("GMLRT_LEVELS", "1")
+    assert st.handout_way == 5 and (buf.cpu().numpy() == small_ref).all() and st.rays == small_st.rays
+    for nparts in (1, 2, 8):
+        out = np.zeros_like(ref)
+        counts = np.zeros(4, dtype=np.int64)
+        for part in range(nparts):
+            p = gmlrt.Params()
+            ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
+            p.tile_rows, p.part, p.nparts = 8, part, nparts
+            rows = gmlrt.part_row_index(2160, 8, part, nparts)
+            buf = torch.full((len(rows), 3840, 3), 0x5A, dtype=torch.uint8, device="cuda:0")
+            for _ in range(2):  # (the second launch reuses the queues the first one filled)
+                st = scene.render_into(p, buf.data_ptr())
+            assert st.handout_way == 5
+            out[rows] = buf.cpu().numpy()
+            counts += np.array([st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits])
+        assert (out == ref).all(), nparts
+        assert tuple(counts) == (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits), nparts
+    scene.close()
 
 
 def test_repeated_render_is_deterministic(gmlrt):
