@@ -83,12 +83,20 @@ def scene_flops_per_ray(blob):
     return total, n_leaves
 
 
-def cpu_baseline():
-    """The f64 CPU oracle (restated reference algorithm) on a bounded sample of the same frame."""
+def cpu_baseline(whole_frame=False):
+    """The f64 CPU oracle (restated reference algorithm) on a bounded sample of the same frame; with whole_frame
+    (--cpu-whole-frame, a quarter of a minute of 16 threads) every row of it with all threads as well."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     prog = oracle_py.OracleProgram(path=SCENE)
+    whole = None
+    if whole_frame:
+        t0 = time.time()
+        _, _, cw = prog.render(0, w=WIDTH, h=HEIGHT, depth=DEPTH, threads=threads)
+        tw = time.time() - t0
+        whole = {"value": round(sum(cw.values()) / tw / 1e6, 4), "unit": "Mrays/s", "cores": threads, "rays": sum(cw.values()),
+                 "wall_s": round(tw, 2), "sample": "every row of the frame"}
     # single thread, as the reference runs: every 120th row (18 rows)
     t0 = time.time()
     _, _, c1 = prog.render(0, w=WIDTH, h=HEIGHT, depth=DEPTH, y0=60, y1=HEIGHT, ystep=120, threads=1)
@@ -104,6 +112,7 @@ def cpu_baseline():
                   "single thread on every 120th row: %.4f Mrays/s (%d rays, %.1f s)"
                   % (rn, tn, threads, r1 / t1 / 1e6, r1, t1),
         "single_thread_value": round(r1 / t1 / 1e6, 4),
+        "whole_frame": whole,
     }
 
 
@@ -113,6 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-whole-frame", action="store_true", help="also time the CPU oracle on every row of the frame (about 15 s of 16 threads)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the first-frame / host-buffer measurements")
     ap.add_argument("--backend", default=None, help="process group backend (default nccl; gloo for CPU rehearsals of the launch path)")
     ap.add_argument("--gather", choices=["host", "rccl"], default="host")
@@ -221,10 +231,13 @@ def main():
     def step():
         buf = outs[n_step[0] % len(outs)]
         n_step[0] += 1
+        if copy_jobs is not None:
+            # the rows this buffer held (the step before the last one's) must have left for the host before the kernel
+            # writes it again: at most len(outs) - 1 copies may still be on their way
+            while copy_jobs.unfinished_tasks >= len(outs):
+                time.sleep(0)
         st = scene.render_into(p, buf.data_ptr(), None, stream)  # returns when the kernel is done
         if copy_jobs is not None:
-            while copy_jobs.unfinished_tasks >= len(outs):  # the buffer about to be rendered into next must have left
-                time.sleep(0)
             copy_jobs.put(buf)
         elif world > 1:
             t = time.perf_counter()
@@ -241,7 +254,9 @@ def main():
 
     # Scene preparation, like the upload above: the library times the pixel tiles in the first launch with a
     # given geometry and tries up to three other ways of handing them out in the launches that follow (gmlrt_kernels.hip).
-    learn_ms = [scene.render_into(p, out.data_ptr(), None, stream).kernel_ms for _ in range(4)]
+    learn = [scene.render_into(p, out.data_ptr(), None, stream) for _ in range(4)]
+    learn_ms = [x.kernel_ms for x in learn]
+    st = learn[-1]
     for _ in range(args.warmup):
         step()
     drain()
@@ -272,6 +287,16 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed_max, kernel_ms_max, gather_s_max = agg.tolist()
     rays_all, hits_all = tot.tolist()
+    # what every rank did, for reading a scaling run: its kernel time per step, how its handle ended up dealing its
+    # tiles, how many tiles it shared among the waves of a block, its share of the rays
+    mine = torch.tensor([kernel_ms / max(args.steps, 1), float(st.handout_way), float(st.tiles_shared), rays / max(args.steps, 1),
+                         gather_s[0] * 1e3 / max(args.steps, 1), elapsed * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=red_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = [t.tolist() for t in per_rank]
 
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
@@ -319,6 +344,11 @@ def main():
             "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
             "gather_ms_per_step": round(gather_s_max * 1e3, 4) if world > 1 else None,
             "learning_launch_kernel_ms": [round(x, 4) for x in learn_ms],
+            "per_rank": {"kernel_ms": [round(r[0], 4) for r in per_rank], "kernel_ms_mean": round(sum(r[0] for r in per_rank) / world, 4),
+                         "handout_way": [int(r[1]) for r in per_rank], "tiles_shared": [int(r[2]) for r in per_rank],
+                         "rays_per_step": [int(r[3]) for r in per_rank], "gather_ms": [round(r[4], 4) for r in per_rank],
+                         "ms_per_step": [round(r[5], 4) for r in per_rank]},
+            "process_group_backend": backend if world > 1 else None,
             "roofline": roofline,
         }
         if args.verify:
@@ -337,7 +367,7 @@ def main():
         if world == 1 and not args.no_host_path:
             line["one_shot"] = one_shot(call)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.cpu_whole_frame)
         print(json.dumps(line), flush=True)
     scene.close()
     if shared is not None:

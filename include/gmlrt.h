@@ -239,14 +239,17 @@ int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8
  * (d_rows, device memory, as gmlrt_render_device left them) to their places in a host framebuffer of `height` rows of
  * `row_bytes` each (w*3 for rgb8, w*24 for f64).  `image` is ordinary host memory; it may be a shared mapping that
  * every rank of a node has open, so that all ranks deliver their rows at once, each over its own GPU's link, and no
- * rank has to receive the others' rows first.  Replaces nothing in the reference (one process, one image). */
+ * rank has to receive the others' rows first.  Calls for one device are serialised inside the library (they share
+ * that device's page-locked staging).  Replaces nothing in the reference (one process, one image). */
 int gmlrt_copy_rows_to_host(int device, const void* d_rows, void* image, size_t row_bytes, int64_t height,
                             int32_t tile_rows, int32_t part, int32_t nparts);
 
-/* gmlrt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments,
- * same pixels, same ray counts; it calls no hipMalloc / hipFree / hipHostMalloc or any other allocating
- * routine.  Everything the kernel needs besides the scene handle (created beforehand) and the caller's
+/* gmlrt_render_device for callers that cannot allocate: tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs between the capture and the replay of a HIP graph of its own.  It has no
+ * counterpart in the reference.  Same arguments, same pixels, same ray counts; it calls no hipMalloc /
+ * hipFree / hipHostMalloc or any other allocating routine.  Like gmlrt_render_device it waits for the
+ * kernel (hipStreamSynchronize on `hip_stream`) and reads the ray counts back, so it cannot itself be
+ * recorded into a graph: a stream that is being captured refuses the synchronisation.  Everything the kernel needs besides the scene handle (created beforehand) and the caller's
  * output buffers -- per-ray event stacks, shading contexts, counters -- lives in a file-scope __device__
  * array of GMLRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
  * As many rays are kept in flight as fit into that array (large CSG trees render slower than through

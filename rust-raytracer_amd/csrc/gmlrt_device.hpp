@@ -81,6 +81,8 @@ struct DeviceScene {
   uint32_t n_vm_regs = 0;       // registers the scene's surface bytecode uses
   void* d_surf = nullptr;       // expanded surface programs
   void* d_leaf_surf = nullptr;  // u32 per leaf: first record of its program
+  void* d_axes = nullptr;       // directions in which a cylinder's test leaves its general case (gmlrt_kernels.hip: cylinder_special_case)
+  uint32_t n_axes = 0;
   gmlrt_blob_header hdr{};
   // workspace, grown on demand and kept for the life of the handle
   void* d_ev_dist = nullptr;

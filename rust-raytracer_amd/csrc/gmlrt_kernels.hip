@@ -88,6 +88,26 @@ constexpr size_t kStagingBytes = 1024 + kMaxGridBlocks * 4 * sizeof(unsigned lon
 
 enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
 
+// The reference's cylinder has two special cases, taken when the ray's direction in the cylinder's object space is
+// within 1e-7 of parallel or of orthogonal to the axis (primitives.rs:644-663): they test only the ray's ORIGIN
+// against the radius (or the two caps) and report the cap (or mantle) hit wherever the ray has drifted to by then,
+// which may lie outside the solid, and so outside every bound built around it.  Such a ray must meet no bound at
+// all.  The host lists the cylinders' axes in world space, one class per distinct direction, each with the cosines
+// beyond / below which a unit direction may be in one of the two cases for some cylinder of the class (generous
+// margins: a flagged ray only takes the slower exact path); the kernel flags a lane whose ray matches a class, keeps
+// it out of the bounded traversal and traces it with the full-list algorithm without bounds.  About one ray in 10^6
+// per class.  kAxisWords doubles a class: axis x y z, cosine above which "parallel", cosine below which "orthogonal".
+constexpr uint32_t kAxisWords = 8;
+__device__ inline bool cylinder_special_case(const double* __restrict__ axes, uint32_t n_axes, V3 d) {
+  bool odd = false;
+  for (uint32_t k = 0; k < n_axes; k++) {
+    const double* __restrict__ a = axes + (size_t)k * kAxisWords;
+    const double c = fabs(d.x * a[0] + d.y * a[1] + d.z * a[2]);
+    odd |= (c >= a[3]) | (c <= a[4]);
+  }
+  return odd;
+}
+
 // Read-only scene sections.  Passed to the kernel as separate `const __restrict__`
 // parameters so that wave-uniform reads of them become scalar loads.
 struct ScenePtrs {
@@ -140,6 +160,9 @@ struct KArgs {
   unsigned int* next_batch;        // kClaimCounters counters, kClaimStride bytes apart: counter g hands out batches g, g + kClaimCounters, ...
   unsigned long long* block_counts;  // per block: primary, shadow, reflect, shaded hits
   unsigned long long* diag;        // diagnostic build only: per-phase cycle and event totals
+  // Directions in which the reference's cylinder test leaves its general case (see kAxisWords): n_axes classes.
+  const double* axes;
+  uint32_t n_axes;
   // Rendering level by level (render_kernel<.., 3>): a launch traces the view rays of ONE bounce level and their
   // shadow rays; a mirror bounce leaves its lane for a device-wide queue, which the next launch traces regrouped.
   uint32_t level;                  // bounce level this launch starts at: 0 camera rays from the pixel tiles, else rays from q_in
@@ -400,7 +423,7 @@ __device__ inline uint32_t merge_any(uint32_t rule, double* __restrict__ evD, ui
 // whose other operand is empty, primitives.rs:295-298).
 __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ leaves, const uint32_t* __restrict__ nodes,
                                               const gmlrt_bound* __restrict__ bounds, uint32_t n_nodes,
-                                              uint32_t n_leaves, bool active, V3 o, V3 d, double* __restrict__ evD,
+                                              uint32_t n_leaves, bool active, bool no_bounds, V3 o, V3 d, double* __restrict__ evD,
                                               uint32_t* __restrict__ evM, uint16_t* __restrict__ lens) {
   Hit h = {false, 0.0, 0u, false};
   if (n_leaves == 1) {
@@ -428,8 +451,9 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
       const double tca = vdot(oc, d);
       const V3 perp = vsub(oc, vmul(d, tca));
       const double r2 = B->radius * B->radius;
-      // any NaN compares false and keeps the subtree
-      const bool miss = !active || vdot(perp, perp) > r2 || (tca < 0.0 && vdot(oc, oc) > r2);
+      // any NaN compares false and keeps the subtree; a lane in one of the cylinder's special cases (no_bounds) keeps
+      // every subtree
+      const bool miss = !active || (!no_bounds && (vdot(perp, perp) > r2 || (tca < 0.0 && vdot(oc, oc) > r2)));
       if (!__ballot(!miss)) {
         lens[level * kBlock + tid] = 0;
         level++;
@@ -931,7 +955,10 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
          dg.kind = dk; dg.k_active[dk] += (unsigned long long)__popcll(__ballot(st_kind(S.st) != kIdle));)
     // ---- one scene traversal for whatever ray each lane holds
     DIAGS(ds_t = __builtin_readcyclecounter();)
-    Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
+    // (a ray in one of the cylinder's special cases takes no part: see cylinder_special_case)
+    Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle && !(A.n_axes && cylinder_special_case(A.axes, A.n_axes, S.d)),
+                            S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
+    if (A.n_axes && st_kind(S.st) != kIdle && cylinder_special_case(A.axes, A.n_axes, S.d)) h.redo = true;
     if constexpr (kShared) {
       if (shared) {
         // (a shadow ray's slice stops at its first candidate at or before the light; the nearest of the four is
@@ -962,7 +989,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       DIAG(dg.n_redo++;)
       // a primitive right under the root's unions gave a span shorter than 1e-10: only the
       // full sweep knows whether it survives (primitives.rs:295-298)
-      const Hit g = intersect_general(leaves, nodes, bounds, A.n_nodes, A.n_leaves, h.redo, S.o, S.d, evD, evM, lens);
+      const Hit g = intersect_general(leaves, nodes, bounds, A.n_nodes, A.n_leaves, h.redo,
+                                      A.n_axes && cylinder_special_case(A.axes, A.n_axes, S.d), S.o, S.d, evD, evM, lens);
       if (h.redo) h = g;
     }
     // ---- then the per-ray bookkeeping, out of line
@@ -1214,6 +1242,7 @@ struct HostStage {
   void* d8 = nullptr;
   void* df = nullptr;
   size_t d8_bytes = 0, df_bytes = 0;
+  std::mutex copy_mu;  // one copy at a time through this stage's slots, stream and events
 };
 constexpr size_t kStageSlotBytes = 4u << 20;
 constexpr size_t kCopyThreads = 4;  // stage index = worker * kCopyThreads + thread
@@ -1235,16 +1264,22 @@ std::string stage_for(int worker, int device, HostStage** out) {
       if (st->stream) (void)hipStreamDestroy(st->stream);
       (void)hipFree(st->d8);
       (void)hipFree(st->df);
-      *st = HostStage();
+      st->device = -1;
+      for (int i = 0; i < HostStage::kSlots; i++) { st->slot[i] = nullptr; st->ev[i] = nullptr; }
+      st->stream = nullptr;
+      st->d8 = st->df = nullptr;
+      st->d8_bytes = st->df_bytes = 0;
     }
     HIP_TRY(hipSetDevice(device));
-    st->device = device;
-    st->slot_bytes = kStageSlotBytes;
-    HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    // (the stage names its device only once all of it exists: a call after a failure half-way builds it again
+    // instead of using null slots)
+    if (!st->stream) HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
     for (int i = 0; i < HostStage::kSlots; i++) {
-      HIP_TRY(hipHostMalloc(&st->slot[i], st->slot_bytes, hipHostMallocDefault));
-      HIP_TRY(hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming));
+      if (!st->slot[i]) HIP_TRY(hipHostMalloc(&st->slot[i], kStageSlotBytes, hipHostMallocDefault));
+      if (!st->ev[i]) HIP_TRY(hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming));
     }
+    st->slot_bytes = kStageSlotBytes;
+    st->device = device;
   }
   *out = st;
   return "";
@@ -1309,6 +1344,8 @@ std::string dev_copy_rows_to_host(int worker, int device, void* image, const voi
   size_t n_threads = total >= (32u << 20) ? kCopyThreads : 1;
   if (n_threads > n_units) n_threads = n_units;
   auto copy_range = [&](HostStage* hs, size_t unit_begin, size_t unit_end) -> std::string {
+    // (calls for one device share its stages: two callers in the same slots would interleave their chunks)
+    std::lock_guard<std::mutex> one_at_a_time(hs->copy_mu);
     if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed in a copy thread";
     const size_t begin = unit_begin * unit, end = std::min(total, unit_end * unit);
     const size_t chunk = hs->slot_bytes / unit * unit;  // whole units per slot
@@ -1563,6 +1600,57 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
       out->key_inv[a] = 1.0 / (hi[a] - lo[a]);  // cells per unit for ONE cell over the box; the launch scales it
     }
   }
+  {
+    // The cylinders' axes in world space, one class per distinct direction (see cylinder_special_case).
+    const gmlrt_blob_header& H = out->hdr;
+    const gmlrt_leaf* L = (const gmlrt_leaf*)((const uint8_t*)blob + H.off_leaves);
+    std::vector<double> axes;
+    for (uint32_t i = 0; i < H.n_leaves; i++) {
+      if (L[i].type != GMLRT_CYLINDER) continue;
+      // object direction u and world direction d of one ray: d = M u up to scale.  In the parallel case the part of u
+      // across the axis is at most 4.5e-4 of the part along it, so d lies within asin(rho) of M e_y with
+      // rho = |M|_F * 4.5e-4 / (|M e_y| - |M|_F * 4.5e-4); in the orthogonal case u's part along the axis is at most
+      // 1e-7 of |u| = |A d| <= |A|_F (A = the inverse's linear part), so |d . n| <= 1e-7 * |A|_F / |A^T e_y| for the
+      // unit normal n = A^T e_y / |A^T e_y| of the planes across the axis.  Axis and normal are classes of their own
+      // (they differ for a sheared cylinder).  All margins doubled.
+      double ax[3], nn[3], fm = 0.0, fa = 0.0;
+      for (int r = 0; r < 3; r++) {
+        ax[r] = L[i].m[r * 4 + 1];
+        nn[r] = L[i].inv_m[4 + r];
+        for (int c = 0; c < 3; c++) { fm += L[i].m[r * 4 + c] * L[i].m[r * 4 + c]; fa += L[i].inv_m[r * 4 + c] * L[i].inv_m[r * 4 + c]; }
+      }
+      fm = std::sqrt(fm); fa = std::sqrt(fa);
+      const double la = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), ln = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+      double hi = -1.0, lo = 2.0;  // (a degenerate transform: every ray takes the exact path)
+      if (la > 0.0 && ln > 0.0 && std::isfinite(fm) && std::isfinite(fa)) {
+        const double spread = fm * 4.5e-4 * 2.0;
+        const double rho = la > spread ? spread / (la - spread) : 1.0;
+        hi = rho < 1.0 ? std::sqrt(1.0 - rho * rho) : -1.0;
+        lo = 1e-7 * fa * 2.0 / ln;  // bound on |d . n| for n of unit length: |(A d)_y| < 1e-7 |A d| <= 1e-7 |A|_F
+        if (!(lo < 1.0)) lo = 2.0;
+        for (int r = 0; r < 3; r++) { ax[r] /= la; nn[r] /= ln; }
+      }
+      auto add = [&](const double v[3], double h_, double l_) {
+        for (size_t k = 0; k < axes.size(); k += kAxisWords) {
+          const double dot = std::fabs(axes[k] * v[0] + axes[k + 1] * v[1] + axes[k + 2] * v[2]);
+          if (dot >= 1.0 - 1e-12) {  // the same direction: one class, the wider margins
+            axes[k + 3] = std::min(axes[k + 3], h_);
+            axes[k + 4] = std::max(axes[k + 4], l_);
+            return;
+          }
+        }
+        axes.insert(axes.end(), {v[0], v[1], v[2], h_, l_, 0.0, 0.0, 0.0});
+      };
+      add(ax, hi, -1.0);   // parallel to the axis
+      add(nn, 2.0, lo);    // across it: orthogonal to the normal of the cap planes
+    }
+    out->n_axes = (uint32_t)(axes.size() / kAxisWords);
+    out->d_axes = nullptr;
+    if (!axes.empty()) {
+      HIP_TRY(hipMalloc(&out->d_axes, axes.size() * sizeof(double)));
+      HIP_TRY(hipMemcpy(out->d_axes, axes.data(), axes.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   HIP_TRY(hipMalloc(&out->d_blob, bytes));
   HIP_TRY(hipMemcpy(out->d_blob, blob, bytes, hipMemcpyHostToDevice));
   {
@@ -1643,6 +1731,7 @@ void dev_scene_destroy(DeviceScene* s) {
   (void)hipFree(s->d_prog);
   (void)hipFree(s->d_surf);
   (void)hipFree(s->d_leaf_surf);
+  (void)hipFree(s->d_axes);
   // the scratch stays for the next scene on this device (one set per device)
   DeviceScene spare;
   spare.device = s->device;
@@ -1688,6 +1777,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.n_prog = s->n_prog;
   A.n_lights = H.n_lights;
   A.max_stack = s->max_stack;
+  A.axes = (const double*)s->d_axes;
+  A.n_axes = s->n_axes;
   for (int i = 0; i < 3; i++) A.amb[i] = p.amb[i];
   // raytracer.rs:131-136
   const double w_world = 2.0 * std::tan(0.5 * (p.fov_deg * (3.14159265358979323846 / 180.0)));

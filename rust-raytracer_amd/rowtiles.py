@@ -58,9 +58,16 @@ class SharedFramebuffer:
         name = [None]
         if self.rank == 0:
             try:
-                path = "/dev/shm/gmlrt_fb_%d_%d" % (os.getpid(), int(os.environ.get("MASTER_PORT", "0")))
-                with open(path, "wb") as f:
-                    f.truncate(int(np.prod(shape)) * np.dtype(dtype).itemsize)
+                path = "/dev/shm/gmlrt_fb_%d_%d_%s" % (os.getpid(), int(os.environ.get("MASTER_PORT", "0")), os.urandom(6).hex())
+                # created here and nowhere else: never follows a link somebody planted, readable by this user only
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                try:
+                    os.ftruncate(fd, int(np.prod(shape)) * np.dtype(dtype).itemsize)
+                except OSError:
+                    os.close(fd)
+                    os.unlink(path)
+                    raise
+                os.close(fd)
                 name = [path]
             except OSError:
                 name = [None]  # no shared memory file system here: every rank learns it below and raises alike
@@ -69,7 +76,15 @@ class SharedFramebuffer:
         if name[0] is None:
             raise RuntimeError("no shared host memory for the framebuffer (/dev/shm not writable)")
         self.path = name[0]
-        self.frame = np.memmap(self.path, dtype=dtype, mode="r+", shape=shape)
+        try:
+            self.frame = np.memmap(self.path, dtype=dtype, mode="r+", shape=shape)
+        except Exception:
+            if self.rank == 0:  # do not leave the file behind
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+            raise
 
     def put_rows_from_device(self, device, d_rows_ptr):
         """This rank's packed rows (device memory) to their image positions."""
