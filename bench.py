@@ -36,26 +36,30 @@ F_PRIM = {0: 61, 1: 60, 2: 70, 3: 77, 4: 47}
 F_SHADE = 150
 PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X vector FP64 (the path computes in f64)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32, the figure the project metric names
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")
+PMC_SUMMARIES = os.path.join(ROOT, "profiles", "r03_*_pmc_summary.json")
 
 
 def measured_counters(workload):
-    """Counters of the headline workload collected with rocprofv3 --pmc (tools/profile_round.sh) and committed under
-    profiles/: executed f64 flops, memory-side bytes and VALU busy fraction, all per launch.  What a launch executes
-    does not depend on when it runs, so the counts are replayed here and divided by the kernel time measured live;
-    they are replayed only while the kernel sources are the ones they were taken from (tools/source_hash.py), and only
-    for the headline workload.  Otherwise None."""
-    if workload != "chess.gml 3840x2160 depth 5":
-        return None
+    """Counters of a workload collected with rocprofv3 --pmc (tools/profile_round.sh) and committed under profiles/:
+    executed f64 flops, memory-side bytes and VALU busy fraction, all per launch.  What a launch executes does not depend
+    on when it runs, so the counts are replayed here and divided by the kernel time measured live; they are replayed
+    only while the kernel sources are the ones they were taken from (tools/source_hash.py) and only for the workload
+    they were taken on.  Returns (derived figures, file name) or (None, None)."""
+    import glob
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from source_hash import source_hash
-        doc = json.load(open(PMC_SUMMARY))
-        if doc.get("kernel_source_hash") != source_hash():
-            return None
-        return doc["derived"]
-    except (OSError, KeyError, ValueError, ImportError):
-        return None
+        now = source_hash()
+    except (OSError, ImportError):
+        return None, None
+    for path in sorted(glob.glob(PMC_SUMMARIES)):
+        try:
+            doc = json.load(open(path))
+            if doc.get("workload") == workload and doc.get("kernel_source_hash") == now:
+                return doc["derived"], os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def spawn_ranks(n, argv):
@@ -308,7 +312,7 @@ def main():
         my_kernel_ms = kernel_ms / args.steps
         workload = "%s %dx%d depth %d" % (os.path.basename(args.scene), w, h, call.params.depth)
         headline = workload == "chess.gml 3840x2160 depth 5"
-        pmc = measured_counters(workload) if world == 1 else None
+        pmc, pmc_file = measured_counters(workload) if world == 1 else (None, None)
         # what the reference's brute force would execute for these rays (every primitive for every ray): a rate of
         # useful results, most of which the kernel obtains by culling; never a fraction of a hardware peak
         equiv = (my_rays * flops_per_ray + my_hits * F_SHADE) / (my_kernel_ms * 1e-3) / 1e12
@@ -324,7 +328,7 @@ def main():
                 "achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP64_VALU_TFLOPS, 4),
                 "frac_of_fp32_valu_peak": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                 "achieved_note": "executed f64 flops per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,TRANS}_F64 + 2 x FMA_F64, x mean "
-                                 "active lanes; %s, taken from these kernel sources) / kernel time measured here" % os.path.basename(PMC_SUMMARY),
+                                 "active lanes; %s, taken from these kernel sources) / kernel time measured here" % pmc_file,
                 "f64_flops_per_launch": pmc["f64_flops_per_launch"],
                 "traffic": pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"],
                 "valu_busy_measured": pmc["valu_busy_fraction"]})

@@ -2,7 +2,8 @@
 """Turns gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the files kept under
 profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <name>_pmc_summary.json (counter means per
 render_kernel launch + derived figures), <name>_bench.json and <name>_bench_under_rocprof.json.
-Usage: tools/summarize_profile.py <tag> <name>     e.g.  tools/summarize_profile.py r01b r01_final"""
+The workload is whatever the bench runs of that tag rendered (their JSON lines name it).
+Usage: tools/summarize_profile.py <tag> <name>     e.g.  tools/summarize_profile.py r03_chess r03_chess"""
 import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_hash import source_hash
@@ -65,8 +66,9 @@ derived = {
 }
 json.dump({
     "kernel_source_hash": source_hash(),
-    "command": "rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)",
-    "workload": "chess.gml 3840x2160 depth 5, 1 MI355X, per render_kernel launch (mean of the %d timed launches of each pass)" % launches,
+    "command": "rocprofv3 --pmc <one group per run> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline <workload> (tools/profile_round.sh)",
+    "workload": under_trace["config"]["workload"],
+    "workload_note": "1 MI355X, per render_kernel launch (mean of the %d timed launches of each pass)" % launches,
     "kernel_trace": {
         "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
         "render_kernel_ms_per_launch": launch_ms,
