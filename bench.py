@@ -87,13 +87,15 @@ def scene_flops_per_ray(blob):
     return total, n_leaves
 
 
-def cpu_baseline(whole_frame=False):
+def cpu_baseline(whole_frame=False, scene_path=SCENE, width=WIDTH, height=HEIGHT, depth=DEPTH):
     """The f64 CPU oracle (restated reference algorithm) on a bounded sample of the same frame; with whole_frame
     (--cpu-whole-frame, a quarter of a minute of 16 threads) every row of it with all threads as well."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    prog = oracle_py.OracleProgram(path=SCENE)
+    prog = oracle_py.OracleProgram(path=scene_path)
+    name = os.path.basename(scene_path)
+    WIDTH, HEIGHT, DEPTH = width, height, depth
     whole = None
     if whole_frame:
         t0 = time.time()
@@ -112,9 +114,9 @@ def cpu_baseline(whole_frame=False):
     r1, rn = sum(c1.values()), sum(cn.values())
     return {
         "value": round(rn / tn / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": "chess.gml 3840x2160 depth 5, every 12th row (180 rows, %d rays, %.1f s wall on %d threads); "
+        "sample": "%s %dx%d depth %d, every 12th row (%d rows, %d rays, %.1f s wall on %d threads); "
                   "single thread on every 120th row: %.4f Mrays/s (%d rays, %.1f s)"
-                  % (rn, tn, threads, r1 / t1 / 1e6, r1, t1),
+                  % (name, WIDTH, HEIGHT, DEPTH, len(range(6, HEIGHT, 12)), rn, tn, threads, r1 / t1 / 1e6, r1, t1),
         "single_thread_value": round(r1 / t1 / 1e6, 4),
         "whole_frame": whole,
     }
@@ -135,7 +137,7 @@ def main():
     ap.add_argument("--scene", default=SCENE)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--depth", type=int, default=None, help="default: 5 for the headline scene, else what the scene file says")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -183,7 +185,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- inputs resident in HBM before the timed region
-    call = gmlrt.Program(path=args.scene).calls[0].with_overrides(args.width, args.height, args.depth)
+    depth = args.depth if args.depth is not None else (DEPTH if os.path.abspath(args.scene) == SCENE else None)
+    call = gmlrt.Program(path=args.scene).calls[0].with_overrides(args.width, args.height, depth)
     w, h = call.params.width, call.params.height
     flops_per_ray, n_leaves = scene_flops_per_ray(call.blob)
     scene = gmlrt.DeviceScene(call.blob, local_rank)
@@ -371,7 +374,7 @@ def main():
         if world == 1 and not args.no_host_path:
             line["one_shot"] = one_shot(call)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_whole_frame)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_whole_frame, args.scene, w, h, call.params.depth)
         print(json.dumps(line), flush=True)
     scene.close()
     if shared is not None:

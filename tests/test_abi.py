@@ -255,13 +255,19 @@ def test_sink_entry_point_rejects_bad_arguments(gmlrt):
 
 
 def test_committed_counters_belong_to_these_kernel_sources():
-    # bench.py replays the executed-flop count of profiles/r02_final_pmc_summary.json only while the kernel sources
-    # hash to what the summary records; a kernel edit without a new profile round would silently drop the roofline
+    # bench.py replays the executed-flop count of a profiles/r03_*_pmc_summary.json only while the kernel sources hash
+    # to what the summary records; a kernel edit without a new profile round would silently drop the roofline
+    import glob
     import json
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_hash import source_hash
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")))
-    assert doc["kernel_source_hash"] == source_hash(), "kernel sources changed: run tools/profile_round.sh + tools/summarize_profile.py"
-    d = doc["derived"]
-    assert 0 < d["f64_flops_per_launch"] / (3.6e-3) / 1e12 / 78.6 < 1
+    docs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_pmc_summary.json")))]
+    head = [d for d in docs if d["workload"] == "chess.gml 3840x2160 depth 5"]
+    assert head, "no counter summary for the headline workload under profiles/"
+    for doc in docs:
+        assert doc["kernel_source_hash"] == source_hash(), \
+            "kernel sources changed since %s was taken: run tools/profile_all.sh + tools/summarize_profile.py" % doc["workload"]
+        d = doc["derived"]
+        ms = doc["kernel_trace"]["mean_of_timed_launches_ms"]
+        assert 0 < d["f64_flops_per_launch"] / (ms * 1e-3) / 1e12 / 78.6 < 1

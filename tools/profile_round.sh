@@ -21,5 +21,6 @@ pass mix SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU
 pass tcc_rd FETCH_SIZE && \
 pass tcc_wr WRITE_SIZE && \
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
-cd $ROOT && timeout -k 10 300 python bench.py $WORKLOAD ${FULL_BENCH:+--cpu-whole-frame} ${FULL_BENCH:---no-cpu-baseline --no-host-path} > $OUT/bench_default.json 2> $OUT/bench_default.err
+if [ -n "$FULL_BENCH" ]; then EXTRA="--cpu-whole-frame"; else EXTRA="--no-cpu-baseline --no-host-path"; fi
+cd $ROOT && timeout -k 10 300 python bench.py $WORKLOAD $EXTRA > $OUT/bench_default.json 2> $OUT/bench_default.err
 ls $OUT
