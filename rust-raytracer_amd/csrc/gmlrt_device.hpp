@@ -99,7 +99,8 @@ struct DeviceScene {
   size_t tiles_alloc = 0;
   bool order_valid = false;     // d_tile_order holds an order for order_key
   bool learn_order = true;      // false for a handle that renders once: learning would never pay
-  // Four ways of handing out the tiles: 0 image order, fixed small batches; 1 the learnt order with its batch
+  // Ways of handing out the tiles (6, the sampled hand-out of launches that know no costs and learn none, is described
+  // in gmlrt_kernels.hip): 0 image order, fixed small batches; 1 the learnt order with its batch
   // table; 2 image order with a batch table of its own; 3 the learnt order with the dearest tiles taken out and
   // rendered first, each by the four waves of a block together (only when the launch has tiles dear enough to set
   // its length); 4 the learnt order, run by the kernel that sorts the rays of a block into its waves before every
@@ -114,6 +115,7 @@ struct DeviceScene {
   void* d_tile_batch_rest = nullptr;
   void* d_tiles_shared = nullptr;
   uint32_t n_batches_rest = 0, n_tiles_shared = 0;
+  void* d_sampled = nullptr;             // sampled hand-out (way 6, launches that know no costs): a word per tile, three lists of tiles, counters
   void* d_xchg = nullptr;                // way 4: ray states on their way between lanes, 16 KB a block
   uint64_t xchg_blocks = 0;
   std::vector<uint32_t> learnt_cost;     // verbose runs only: the costs the tables were made from

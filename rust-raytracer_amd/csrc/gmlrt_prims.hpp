@@ -21,13 +21,18 @@ __device__ inline V3 vnormalize(V3 a) { return vmul(a, 1.0 / sqrt(vdot(a, a))); 
 
 // ---------------------------------------------------------------- primitives
 // Ray into object space: primitives.rs:350-354 (same prologue in all five).
-__device__ inline void to_object(const double* __restrict__ im, V3 o, V3 d, double& scale, V3& rd, V3& rp) {
-  V3 td = {im[0] * d.x + im[1] * d.y + im[2] * d.z, im[4] * d.x + im[5] * d.y + im[6] * d.z,
-           im[8] * d.x + im[9] * d.y + im[10] * d.z};
-  scale = 1.0 / sqrt(vdot(td, td));
-  rd = vmul(td, scale);
+// (in two steps, so that a caller can look at the ray before it pays for the square root and the division)
+__device__ inline void to_object_raw(const double* __restrict__ im, V3 o, V3 d, V3& td, V3& rp) {
+  td = {im[0] * d.x + im[1] * d.y + im[2] * d.z, im[4] * d.x + im[5] * d.y + im[6] * d.z,
+        im[8] * d.x + im[9] * d.y + im[10] * d.z};
   rp = {im[0] * o.x + im[1] * o.y + im[2] * o.z + im[3], im[4] * o.x + im[5] * o.y + im[6] * o.z + im[7],
         im[8] * o.x + im[9] * o.y + im[10] * o.z + im[11]};
+}
+__device__ inline void to_object(const double* __restrict__ im, V3 o, V3 d, double& scale, V3& rd, V3& rp) {
+  V3 td;
+  to_object_raw(im, o, d, td, rp);
+  scale = 1.0 / sqrt(vdot(td, td));
+  rd = vmul(td, scale);
 }
 
 // Result of one primitive test: bit 0 = an Entry event (tA, fA), bit 1 = an Exit event (tB, fB).
@@ -171,6 +176,91 @@ __device__ inline PrimHit isect_plane(V3 p, V3 d) {
   if (denom > 0.0) { r.bits = 2; r.tB = t; }
   else { r.bits = 1; r.tA = t; }
   return r;
+}
+
+// ---------------------------------------------------------------- a look before the test
+// Can the ray p + t * d have an Entry event on the unit primitive at all?  d is the direction in object space BEFORE
+// it is normalised (a = d . d), so the answer costs neither the square root nor the division of to_object, and none
+// of the intersector's.  "false" is a promise: the intersector above, given p and d / |d|, reports no Entry (bit 0
+// of PrimHit::bits) for this ray.  "true" promises nothing.
+//
+// Every condition below is a consequence of the ray having an Entry, in real arithmetic, relaxed by a slack of
+// 1e-9 relative to the magnitudes of the terms it compares (1e-5 where the hardware's approximate reciprocal and
+// square root are used: they are good to 2^-23).  The intersectors' own rounding errors are of the order of 1e-15 of
+// the same magnitudes, so a ray turned away here is turned away by them too.  The arithmetic here need not be
+// reproducible, only conservative: fused operations are welcome, and a NaN anywhere makes a comparison false,
+// which keeps the ray.
+__device__ inline bool prim_may_enter(uint32_t type, V3 p, V3 d, double a) {
+  constexpr double kE = 1e-9, kA = 1e-5;
+  switch (type) {
+    case GMLRT_SPHERE: {
+      // Entry <=> the line passes within the radius, the origin lies outside and the sphere lies ahead
+      const double S = -__builtin_fma(p.x, d.x, __builtin_fma(p.y, d.y, p.z * d.z));  // s * |d|
+      const double lsq = __builtin_fma(p.x, p.x, __builtin_fma(p.y, p.y, p.z * p.z));
+      const double la = lsq * a;
+      const bool behind = (S < 0.0) & (S * S > 1e-24 * la);
+      const bool inside = lsq < 1.0 - kE;
+      const bool wide = __builtin_fma(-S, S, la) > __builtin_fma(kE, la + a, a);
+      return !(behind | inside | wide);
+    }
+    case GMLRT_CUBE: {
+      // slabs with approximate reciprocals; Entry <=> the three intervals overlap and the overlap begins ahead
+      const double rx = __builtin_amdgcn_rcp(d.x), ry = __builtin_amdgcn_rcp(d.y), rz = __builtin_amdgcn_rcp(d.z);
+      const double x0 = -p.x * rx, x1 = (1.0 - p.x) * rx, y0 = -p.y * ry, y1 = (1.0 - p.y) * ry, z0 = -p.z * rz, z1 = (1.0 - p.z) * rz;
+      const double tmin = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+      const double tmax = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+      // (1 / |d_i| >= 1 / |d|: the second term is 1e-9 of the cube's edge, in units of t)
+      const double m = __builtin_fma(kA, fabs(tmin) + fabs(tmax), kE * fmin(fmin(fabs(rx), fabs(ry)), fabs(rz)));
+      // The intersector leaves out a slab whose direction component is below 1e-15 of the direction's length and
+      // then takes an origin ON a face of that slab for inside, whatever the ray does from there: a ray with such a
+      // component (below 1e-14, to be clear of the threshold) is not judged here.
+      const double tiny = 1e-28 * a;
+      const bool flat = (d.x * d.x <= tiny) | (d.y * d.y <= tiny) | (d.z * d.z <= tiny);
+      return flat | !((tmin - tmax > m) | (tmin < -m));
+    }
+    case GMLRT_CYLINDER: {
+      const double A = __builtin_fma(d.x, d.x, d.z * d.z), Bh = __builtin_fma(p.x, d.x, p.z * d.z);
+      const double r2 = __builtin_fma(p.x, p.x, p.z * p.z), C = r2 - 1.0;
+      // beyond a cap and not heading back; outside the mantle and heading away from the axis; inside the solid
+      const bool beyond = ((p.y > 1.0 + kE) & (d.y >= 0.0)) | ((p.y < -kE) & (d.y <= 0.0));
+      const bool away = (C > kE * (r2 + 1.0)) & (Bh > 0.0) & (Bh * Bh > 1e-20 * A * r2);
+      const bool inside = (C < -kE) & (p.y > kE) & (p.y < 1.0 - kE);
+      // the line misses the infinite cylinder
+      // (the slack is taken from the magnitudes of the terms, not of their sums: Bh and C are differences that may cancel)
+      const double disc = __builtin_fma(Bh, Bh, -A * C);
+      const double m1 = fabs(p.x * d.x) + fabs(p.z * d.z);
+      const bool wide = disc < -kE * __builtin_fma(m1, m1, A * (r2 + 1.0));
+      // the chord inside the infinite cylinder lies beyond one cap with both ends.  Not asked of a ray within 1e-3 of
+      // parallel or orthogonal to the axis: there the intersector leaves its general case and looks at the origin only.
+      const double rt = __builtin_amdgcn_sqrt(fmax(disc, 0.0)), rA = __builtin_amdgcn_rcp(A);
+      const double ya = __builtin_fma((-Bh - rt) * rA, d.y, p.y), yb = __builtin_fma((-Bh + rt) * rA, d.y, p.y);
+      const double m = kA * __builtin_fma((fabs(Bh) + rt) * rA, fabs(d.y), fabs(p.y) + 1.0);
+      const bool general = (d.y * d.y > 1e-6 * a) & (A > 1e-6 * a);
+      const bool off = general & (((ya > 1.0 + m) & (yb > 1.0 + m)) | ((ya < -m) & (yb < -m)));
+      return !(beyond | away | inside | wide | off);
+    }
+    case GMLRT_CONE: {
+      const double A = __builtin_fma(d.x, d.x, __builtin_fma(d.z, d.z, -d.y * d.y));
+      const double Bh = __builtin_fma(p.x, d.x, __builtin_fma(p.z, d.z, -p.y * d.y));
+      const double r2 = __builtin_fma(p.x, p.x, p.z * p.z), py2 = p.y * p.y, C = r2 - py2;
+      // every point of the cone has 0 <= y <= 1: beyond that range and not heading back, all events lie behind
+      const bool beyond = ((p.y > 1.0 + kE) & (d.y >= 0.0)) | ((p.y < -kE) & (d.y <= 0.0));
+      // (the slack is taken from the magnitudes of the terms, not of their sums: A, Bh and C are differences that may
+      // cancel, and where they do, a ray along the mantle, the intersector's own roots are rounding noise)
+      const double disc = __builtin_fma(Bh, Bh, -A * C);
+      const double m1 = fabs(p.x * d.x) + fabs(p.z * d.z) + fabs(p.y * d.y);
+      const bool wide = disc < -kE * __builtin_fma(m1, m1, a * (r2 + py2));
+      // both crossings of the double cone lie outside 0 <= y <= 1 (asked only where the quadratic is well conditioned)
+      const double rt = __builtin_amdgcn_sqrt(fmax(disc, 0.0)), rA = __builtin_amdgcn_rcp(A);
+      const double ya = __builtin_fma((-Bh - rt) * rA, d.y, p.y), yb = __builtin_fma((-Bh + rt) * rA, d.y, p.y);
+      const double m = kA * __builtin_fma((fabs(Bh) + rt) * fabs(rA), fabs(d.y), fabs(p.y) + 1.0);
+      const bool off = (fabs(A) > 1e-6 * a) & ((ya > 1.0 + m) | (ya < -m)) & ((yb > 1.0 + m) | (yb < -m));
+      return !(beyond | wide | off);
+    }
+    default:
+      // plane: an Entry <=> the ray heads into y <= 0 from y >= 0 (exact: the signs survive the normalisation)
+      return !(d.y >= 0.0) & !(p.y < 0.0);
+  }
 }
 
 __device__ inline PrimHit isect_prim(uint32_t type, V3 rp, V3 rd) {

@@ -18,6 +18,11 @@
 #ifndef GMLRT_TRAVERSE_INLINE
 #define GMLRT_TRAVERSE_INLINE inline
 #endif
+#if defined(GMLRT_LEAF_LOOK_CHECK) && GMLRT_LEAF_LOOK
+#define LOOKCHK(...) __VA_ARGS__
+#else
+#define LOOKCHK(...)
+#endif
 // Per-lane flags of the traversal, kept as bits of one integer register.  (As separate
 // booleans they are wave masks in scalar register pairs, and every join of control flow
 // in the loop below merges each of them with three scalar instructions.)  "A candidate has
@@ -72,6 +77,8 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
     // per record.  (The program is padded so that this never reads past its buffer.)
     u32x16 R = *(const u32x16*)(const void*)(prog + pc);
     uint32_t kf = R[0];
+    DIAG(dg.c_t = __builtin_readcyclecounter();)
+#define DIAG_KIND(q) DIAG({ const unsigned long long n_ = __builtin_readcyclecounter(); dg.c_kind[q] += n_ - dg.c_t; dg.n_kind[q]++; dg.c_t = n_; })
     level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);  // wave-uniform by construction: say so
     // Bounds come in runs (the way down a hierarchy) and change nothing a lane carries, only where
     // the wave reads next: they get a loop of their own, whose only state is scalar.  (In one loop
@@ -138,18 +145,41 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
         }
         kf = R[0];
       } while (kf & (kRecIsBox | kRecIsBound));
+      DIAG_KIND(0);
     }
     if (kf & kRecIsLeaf) {
       // ProgLeaf: leaf, inv_m[12]; the matrix's last five elements lie beyond the first 64 bytes
       const ProgLeaf* __restrict__ L = (const ProgLeaf*)(prog + pc);
       const double im[12] = {REC_F64(0), REC_F64(1), REC_F64(2), REC_F64(3), REC_F64(4), REC_F64(5), REC_F64(6),
                              L->inv_m[7], L->inv_m[8], L->inv_m[9], L->inv_m[10], L->inv_m[11]};
-      double scale; V3 rd, rp;
-      to_object(im, o, d, scale, rd, rp);
-      PrimHit ph = isect_prim((kf >> 16) & 7u, rp, rd);
-      const uint32_t leaf = R[1];
+      V3 td, rp;
+      to_object_raw(im, o, d, td, rp);
+      const double td2 = vdot(td, td);
       DIAG(dg.n_leaf++;)
       pc += (uint32_t)sizeof(ProgLeaf);
+#if GMLRT_LEAF_LOOK
+      // A look at the rays in the primitive's object space before the direction is normalised: when no active lane's
+      // ray can have an Entry on the primitive (prim_may_enter: conservative), the leaf's list is empty for every
+      // lane that matters (a list without an Entry counts as empty, see below) and the square root, the division
+      // and the intersector are skipped.  In half of all leaf tests of a frame no lane has an Entry.
+      const bool may = ((fl & kFlActive) != 0) & prim_may_enter((kf >> 16) & 7u, rp, td, td2);
+#ifndef GMLRT_LEAF_LOOK_CHECK
+      if (!__ballot(may)) {
+        DIAG(dg.l_nohit++; if (dg.leaf_dbg && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) {
+               atomicAdd(&dg.leaf_dbg[R[1] * kLeafDbg], 1ull); atomicAdd(&dg.leaf_dbg[R[1] * kLeafDbg + 1], 1ull); atomicAdd(&dg.leaf_dbg[R[1] * kLeafDbg + 3], 1ull); })
+        if (!(kf & kRecFlag)) {
+          lens[level * kBlock + tid] = 0;
+          level++;
+        }
+        DIAG_KIND(1);
+        continue;
+      }
+#endif
+#endif
+      const double scale = 1.0 / sqrt(td2);
+      const V3 rd = vmul(td, scale);
+      PrimHit ph = isect_prim((kf >> 16) & 7u, rp, rd);
+      const uint32_t leaf = R[1];
       // a list that starts with Exit never raises its operand's counter above zero
       // (primitives.rs:254-293 start both counters at 0): same as no list at all
       const bool entry = ((fl & kFlActive) != 0) & ((ph.bits & 1) != 0);
@@ -158,8 +188,14 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       DIAG(dg.l_lanes += (unsigned long long)__popcll(__ballot((fl & kFlActive) != 0)); dg.l_hits += (unsigned long long)__popcll(__ballot(entry));
            if (!__ballot(entry)) dg.l_nohit++;
            { const unsigned long long be = __ballot(entry);
-             if (dg.leaf_dbg && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) { atomicAdd(&dg.leaf_dbg[leaf * 3], 1ull); if (!be) atomicAdd(&dg.leaf_dbg[leaf * 3 + 1], 1ull);
-               atomicAdd(&dg.leaf_dbg[leaf * 3 + 2], (unsigned long long)__popcll(be)); } })
+             // (check build: the look decides nothing; counted are the tests it would have skipped and the lanes with
+             // an Entry that it turned away, which must be none)
+             LOOKCHK(const unsigned long long bm = __ballot(may); const unsigned long long bv = __ballot(entry & !may);)
+             if (dg.leaf_dbg && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) { atomicAdd(&dg.leaf_dbg[leaf * kLeafDbg], 1ull); if (!be) atomicAdd(&dg.leaf_dbg[leaf * kLeafDbg + 1], 1ull);
+               atomicAdd(&dg.leaf_dbg[leaf * kLeafDbg + 2], (unsigned long long)__popcll(be));
+               LOOKCHK(if (!bm) atomicAdd(&dg.leaf_dbg[leaf * kLeafDbg + 3], 1ull);
+                       atomicAdd(&dg.leaf_dbg[leaf * kLeafDbg + 4], (unsigned long long)__popcll(bv));)
+             } })
       if (kf & kRecFlag) {
         // frontier leaf: no list, just a candidate for the nearest first Entry
         // (selects, not branches: as nested conditions this was five levels of lane-mask bookkeeping for eight
@@ -172,6 +208,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
 #if GMLRT_TSTOP
         fl &= (entry & ((best_m & kHitAny) != 0) & (best <= t_stop)) ? ~kFlActive : ~0u;
 #endif
+        DIAG_KIND(2);
         continue;
       }
       uint32_t n = 0;
@@ -188,6 +225,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       lens[level * kBlock + tid] = (uint16_t)n;
       sp += n & 0x7FFFu;
       level++;
+      DIAG_KIND(3);
       continue;
     }
     if (kf & kRecIsOp) {
@@ -210,6 +248,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       sp = a0 + lout;
       level--;
       pc += (uint32_t)sizeof(ProgSmall);
+      DIAG(if (__ballot(general)) { DIAG_KIND(5); } else { DIAG_KIND(4); })
       continue;
     }
     if (kf & kRecIsSkip) {
@@ -218,6 +257,7 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       // second operand and the operator are jumped over
       const uint32_t l = lens[(level - 1) * kBlock + tid] & 0x7FFFu;
       pc = __ballot(l != 0) ? pc + (uint32_t)sizeof(ProgSmall) : R[1];
+      DIAG_KIND(6);
       continue;
     }
     if (kf & kRecIsTake) {
@@ -241,10 +281,12 @@ __device__ GMLRT_TRAVERSE_INLINE Hit intersect_first(const gmlrt_leaf* __restric
       sp = 0;
       level = 0;
       pc += (uint32_t)sizeof(ProgSmall);
+      DIAG_KIND(7);
       continue;
     }
     break;  // kRecEnd
   }
+#undef DIAG_KIND
 #undef REC_F64
 #undef REC_F32
   h.any = (best_m & kHitAny) != 0;

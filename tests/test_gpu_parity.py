@@ -255,6 +255,33 @@ def test_level_by_level_rendering_of_row_partitions_and_full_frames(gmlrt, oracl
     scene.close()
 
 
+@pytest.mark.parametrize("name,size,depth,tune", [
+    ("chess", (1921, 1101), 5, None),                       # ragged tiles and groups
+    ("chess", (1920, 1104), 4, "128,192,240,2,3,5"),        # classes that open early: most tiles go through the lists
+    ("fractal", (2048, 1040), 3, "64,128,192,1,2,3"),
+])
+def test_sampled_hand_out_of_a_frame_rendered_once(gmlrt, oracle, monkeypatch, name, size, depth, tune):
+    # GMLRT_SAMPLED=1: a launch without tile costs renders one tile of every 4 x 4 group first, and the groups of samples
+    # that run long are handed out before the plain order, from device-wide lists; every tile is claimed by an atomic
+    # exchange, so every pixel and every ray count must be what the plain hand-out gives, and a spread of rows the oracle's
+    call = gmlrt.Program(path=os.path.join(SCENES, name + ".gml")).calls[0].with_overrides(size[0], size[1], depth)
+    other = gmlrt.Program(path=os.path.join(SCENES, "spheres.gml")).calls[0]
+    monkeypatch.delenv("GMLRT_SAMPLED", raising=False)
+    ref, _, st_ref = gmlrt.render(call)
+    assert st_ref.handout_way != 6
+    rows, o_ref = _oracle_rows(oracle, name, size, depth, n_rows=7)
+    assert (ref[rows] == o_ref).all()
+    monkeypatch.setenv("GMLRT_SAMPLED", "1")
+    if tune:
+        monkeypatch.setenv("GMLRT_SM_TUNE", tune)
+    for _ in range(2):
+        gmlrt.render(other)  # (so that the library keeps no handle of the frame: a kept handle learns an order instead)
+        img, _, st = gmlrt.render(call)
+        assert st.handout_way == 6
+        assert (img == ref).all()
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits) == (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits)
+
+
 def test_repeated_render_is_deterministic(gmlrt):
     prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
     a, _, sa = gmlrt.render(prog.calls[0])
