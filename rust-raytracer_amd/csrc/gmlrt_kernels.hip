@@ -261,6 +261,10 @@ struct ShadeArgs {
   uint32_t* surf_error;        // set to 1 by a lane whose own surface program raised GMLRT_SOP_TRAP
   double* ctx;                 // context records of all waves (wave-major, then field, then lane)
   uint32_t vm_lds_off;         // byte offset of the block's register / hot-context region in its LDS
+  // the camera (raytracer.rs:131-142) and the row layout of the launch: the per-ray code makes the camera ray of a
+  // pixel again where it needs it (highlight, first bounce) instead of keeping it in the lane's context record
+  double c_x, c_y, pw;
+  int32_t w, tile_rows, part, nparts, band_row0;
   uint32_t parked_stride;      // level-by-level rendering: parked records per pixel (the depth of the call)
   double* parked;              // ... and the records: 8 words for pixel p and level l at (p * parked_stride + l) * 8
 };
@@ -1181,9 +1185,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- one scene traversal for whatever ray each lane holds
     DIAGS(ds_t = __builtin_readcyclecounter();)
     // (a ray in one of the cylinder's special cases takes no part: see cylinder_special_case)
-    Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle && !(A.n_axes && cylinder_special_case(A.axes, A.n_axes, S.d)),
-                            S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
-    if (A.n_axes && st_kind(S.st) != kIdle && cylinder_special_case(A.axes, A.n_axes, S.d)) h.redo = true;
+    const bool odd_ray = A.n_axes && st_kind(S.st) != kIdle && cylinder_special_case(A.axes, A.n_axes, S.d);  // (looked at once a round)
+    Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle && !odd_ray, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
+    if (odd_ray) h.redo = true;
     if constexpr (kShared) {
       if (shared) {
         // (a shadow ray's slice stops at its first candidate at or before the light; the nearest of the four is
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       // a primitive right under the root's unions gave a span shorter than 1e-10: only the
       // full sweep knows whether it survives (primitives.rs:295-298)
       const Hit g = intersect_general(leaves, nodes, bounds, A.n_nodes, A.n_leaves, h.redo,
-                                      A.n_axes && cylinder_special_case(A.axes, A.n_axes, S.d), S.o, S.d, evD, evM, lens);
+                                      odd_ray, S.o, S.d, evD, evM, lens);
       if (h.redo) h = g;
     }
     // ---- then the per-ray bookkeeping, out of line
@@ -2345,6 +2349,8 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.surf_prog = (const SurfInstr*)s->d_surf;
   SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
   SA.ctx = A.ctx;
+  SA.c_x = A.c_x; SA.c_y = A.c_y; SA.pw = A.pw;
+  SA.w = A.w; SA.tile_rows = A.tile_rows; SA.part = A.part; SA.nparts = A.nparts; SA.band_row0 = A.band_row0;
   SA.vm_lds_off = A.vm_lds_off;
   SA.parked = levels ? (double*)s->d_parked : nullptr;
   SA.parked_stride = (uint32_t)p.depth;

@@ -49,6 +49,22 @@ __device__ inline void cold_set3(double* ctx, int f, V3 v) { COLD(f) = v.x; COLD
 // kLevels: the frame is rendered level by level; a bounce ray leaves this lane (the caller queues it for the next
 // launch), so what trace() keeps across its recursive call, (c, sc, ks), is parked per PIXEL and level, where the
 // lane that ends the pixel's chain of bounces, in whatever launch, finds it.
+// The direction of the camera ray of output pixel `pix` (row-in-band * w + x), made the way the pixel hand-out of the
+// kernel makes it (GMLRT_CAMERA_RAY; raytracer.rs:138-142): the same operations on the same values, so the same bits.
+__device__ inline V3 camera_ray_dir(const ShadeArgs* __restrict__ SA, uint32_t pix) {
+  const uint32_t w = (uint32_t)SA->w;
+  const uint32_t yl = pix / w, x = pix - yl * w;
+  const uint32_t yp = yl + (uint32_t)SA->band_row0;
+  uint32_t y = yp;
+  if (SA->nparts > 1) {
+    const uint32_t k = yp / (uint32_t)SA->tile_rows;
+    y = ((uint32_t)SA->part + k * (uint32_t)SA->nparts) * (uint32_t)SA->tile_rows + yp % (uint32_t)SA->tile_rows;
+  }
+  const double xf = (double)x, yf = (double)y;
+  const V3 dir = {SA->c_x + (xf + 0.5) * SA->pw, SA->c_y - (yf + 0.5) * SA->pw, 1.0};
+  return vnormalize(dir);
+}
+
 template <bool kLds, bool kSlot, bool kLevels = false>
 __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const double h_dist, const uint32_t h_meta_any,
                                                   const ShadeArgs* __restrict__ SA_v, uint32_t* __restrict__ events_out) {
@@ -95,9 +111,13 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       const double od = (h_meta & kOrigExit) ? ph.tB : ph.tA;
       opos = vadd(rp, vmul(rd, od));
       prim_uv(type, face, opos, u, v);
-      // the view ray is needed again for the highlight and the bounce; S is free from here on
-      cold_set3(ctx, C_RPOS, S.o);
-      cold_set3(ctx, C_RDIR, S.d);
+      // the view ray is needed again for the highlight and the bounce; S is free from here on.  A camera ray is not
+      // kept: its origin is the eye and its direction follows from the pixel (camera_ray_dir), which is cheaper than
+      // 48 bytes a lane out to memory and back for every pixel that shows anything.
+      if (kLevels || level != 0) {
+        cold_set3(ctx, C_RPOS, S.o);
+        cold_set3(ctx, C_RDIR, S.d);
+      }
     }
   }
 
@@ -189,7 +209,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       if (HOT(H_KD) > 0.0) HOT_SET3(H_DIFF, vadd(HOT_GET3(H_DIFF), vmul(ic, df)));
       if (HOT(H_KS) > 0.0) {
         // get_specular, raytracer.rs:34-42
-        const V3 raypos = cold_get3(ctx, C_RPOS);
+        const V3 raypos = (kLevels || level != 0) ? cold_get3(ctx, C_RPOS) : V3{0.0, 0.0, -1.0};
         const V3 halfway = vnormalize(vadd(ldir, vnormalize(vsub(raypos, pos))));
         const double sp = vdot(normal, halfway);
         V3 add = {0.0, 0.0, 0.0};
@@ -230,7 +250,7 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
       const V3 c0 = vmul(vcmul({SA->amb[0], SA->amb[1], SA->amb[2]}, sc), kd);  // get_ambient, raytracer.rs:30-32
       const V3 c = vadd(c0, vadd(vmul(HOT_GET3(H_DIFF), kd), vmul(HOT_GET3(H_SPEC), ks)));
       if (ks > 0.0 && (SA->depth - level) > 0) {
-        const V3 raydir = cold_get3(ctx, C_RDIR);
+        const V3 raydir = (kLevels || level != 0) ? cold_get3(ctx, C_RDIR) : camera_ray_dir(SA, S.pix);
         const V3 refl = vnormalize(vsub(raydir, vmul(normal, 2.0 * vdot(raydir, normal))));
         // park (c, sc, ks) until the bounce below returns
         if constexpr (kLevels) {
