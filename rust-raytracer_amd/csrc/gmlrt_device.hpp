@@ -83,6 +83,8 @@ struct DeviceScene {
   void* d_leaf_surf = nullptr;  // u32 per leaf: first record of its program
   void* d_axes = nullptr;       // directions in which a cylinder's test leaves its general case (gmlrt_kernels.hip: cylinder_special_case)
   uint32_t n_axes = 0;
+  std::vector<double> h_axes;   // host copy of d_axes (the first classes travel in the launch record as well)
+  uint32_t n_cone_forms = 0;    // quadratic forms, behind the cylinders' classes in d_axes: directions along a cone's mantle (cone_special_case)
   gmlrt_blob_header hdr{};
   // workspace, grown on demand and kept for the life of the handle
   void* d_ev_dist = nullptr;

@@ -108,6 +108,43 @@ __device__ inline bool cylinder_special_case(const double* __restrict__ axes, ui
   return odd;
 }
 
+// The reference's cone has a case of the same kind: for a ray that runs along the mantle (parallel to a generator)
+// the quadratic of primitives.rs:778-792 loses its leading coefficient, a = dx^2 + dz^2 - dy^2 comes out as a few
+// units of rounding, and the "root" (-b + sqrt(b^2 - 4ac)) / 2a is the quotient of two rounding errors.  When that
+// number happens to give a height between 0 and 1 the reference takes it for the one crossing of the mantle and adds
+// the crossing of the base PLANE as the other (primitives.rs:844-848), wherever that lies: a hit that need not be
+// anywhere near the solid, and that every bound around the solid culls.  (Found by the lattice fuzz: one scene in
+// 20 000, a light at 45 degrees over a cone on its side.)  A ray is in the regime when |a| <= 1e-6 of its squared
+// length in the cone's object space; a = d^T (M^T J M) d for the world direction d, M the linear part of the cone's
+// inverse transform and J = diag(1, -1, 1), so the host lists one symmetric form per distinct cone shape and
+// orientation, scaled by 1 / trace(M^T M) (then |d_object|^2 <= |d|^2 and the bound is conservative), and the kernel
+// flags a lane whose unit direction gives |d^T Q d| <= 1e-6 for some form; such a lane is traced exactly and without
+// bounds, like a cylinder's.  kAxisWords doubles a form: q00 q11 q22 2q01 2q02 2q12 bound.
+__device__ inline bool cone_special_case(const double* __restrict__ forms, uint32_t n_forms, V3 d) {
+  const double xx = d.x * d.x, yy = d.y * d.y, zz = d.z * d.z, xy = d.x * d.y, xz = d.x * d.z, yz = d.y * d.z;
+  bool odd = false;
+  for (uint32_t k = 0; k < n_forms; k++) {
+    const double* __restrict__ f = forms + (size_t)k * kAxisWords;
+    const double q = __builtin_fma(f[0], xx, __builtin_fma(f[1], yy, __builtin_fma(f[2], zz, __builtin_fma(f[3], xy, __builtin_fma(f[4], xz, f[5] * yz)))));
+    odd |= !(fabs(q) > f[6]);
+  }
+  return odd;
+}
+
+// Both looks at a new ray's direction.  The answer travels with the ray as a bit of its state word (kStOdd), set where
+// the ray is made: in the per-ray code, which is out of line and has registers to spare.  (Asked in the kernel's main
+// loop, once a round, the loop over the classes cost the traversal next to it 5 % on the chess frame: scalar registers
+// held across it.)
+__device__ inline bool ray_special_case(const double* __restrict__ axes, uint32_t n_axes, uint32_t n_forms, V3 d) {
+  return (n_axes && cylinder_special_case(axes, n_axes, d)) || (n_forms && cone_special_case(axes + (size_t)n_axes * kAxisWords, n_forms, d));
+}
+constexpr uint32_t kOddInline = 4;
+constexpr double kConeFormBound = 1e-6;
+constexpr uint32_t kStOdd = 1u << 24;  // (not in the kernel that regroups the rays of a block, where bits 31..24 name the ray's context slot)
+__device__ __noinline__ uint32_t ray_special_bit(const double* __restrict__ axes, uint32_t n_axes, uint32_t n_forms, double dx, double dy, double dz) {
+  return ray_special_case(axes, n_axes, n_forms, V3{dx, dy, dz}) ? kStOdd : 0u;
+}
+
 // Read-only scene sections.  Passed to the kernel as separate `const __restrict__`
 // parameters so that wave-uniform reads of them become scalar loads.
 struct ScenePtrs {
@@ -164,6 +201,7 @@ struct KArgs {
   // Directions in which the reference's cylinder test leaves its general case (see kAxisWords): n_axes classes.
   const double* axes;
   uint32_t n_axes;
+  uint32_t n_cone_forms;  // the cones' forms follow the cylinders' classes in `axes` (see cone_special_case)
   // Rendering level by level (render_kernel<.., 3>): a launch traces the view rays of ONE bounce level and their
   // shadow rays; a mirror bounce leaves its lane for a device-wide queue, which the next launch traces regrouped.
   uint32_t level;                  // bounce level this launch starts at: 0 camera rays from the pixel tiles, else rays from q_in
@@ -265,6 +303,13 @@ struct ShadeArgs {
   // pixel again where it needs it (highlight, first bounce) instead of keeping it in the lane's context record
   double c_x, c_y, pw;
   int32_t w, tile_rows, part, nparts, band_row0;
+  const double* axes;          // the cylinders' and cones' special directions (see ray_special_case)
+  uint32_t n_axes, n_cone_forms;
+  // the first kOddInline classes of each kind once more, in the record itself: the per-ray code fetches them in one round
+  // of scalar loads, without first fetching a pointer (slots beyond a scene's classes hold classes that no ray matches)
+  double odd_axis[kOddInline][4];  // axis x y z, cosine above which "parallel"
+  double odd_axis_lo[kOddInline];  // cosine below which "orthogonal"
+  double odd_form[kOddInline][6];  // q00 q11 q22 2q01 2q02 2q12 (the bound is 1e-6 for every form)
   uint32_t parked_stride;      // level-by-level rendering: parked records per pixel (the depth of the call)
   double* parked;              // ... and the records: 8 words for pixel p and level l at (p * parked_stride + l) * 8
 };
@@ -750,7 +795,8 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       S.o = {0.0, 0.0, -1.0};                                                                                      \
       S.d = vnormalize(dir);                                                                                       \
       S.t_stop = -__builtin_inff();                                                                                \
-      S.st = kView | (kRegroup ? S.st & 0xFF000000u : 0u); /* level 0 */                                           \
+      S.st = kView | (kRegroup ? S.st & 0xFF000000u                                                                \
+                               : (A.n_axes | A.n_cone_forms) ? ray_special_bit(A.axes, A.n_axes, A.n_cone_forms, S.d.x, S.d.y, S.d.z) : 0u); /* level 0 */ \
       S.pix = yl * (uint32_t)A.w + x;                                                                              \
     }                                                                                                              \
   } while (0)
@@ -1126,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
             S.d = {r1.y, r2.x, r2.y};
             S.pix = (uint32_t)__builtin_bit_cast(uint64_t, r3.x);
             S.t_stop = -__builtin_inff();
-            S.st = kView | (A.level << 2);
+            S.st = kView | (A.level << 2) | ((A.n_axes | A.n_cone_forms) ? ray_special_bit(A.axes, A.n_axes, A.n_cone_forms, S.d.x, S.d.y, S.d.z) : 0u);
           }
         } else {
           GMLRT_CAMERA_RAY(cur_tile, (tile_base + rank) & 63u);
@@ -1185,7 +1231,9 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
     // ---- one scene traversal for whatever ray each lane holds
     DIAGS(ds_t = __builtin_readcyclecounter();)
     // (a ray in one of the cylinder's special cases takes no part: see cylinder_special_case)
-    const bool odd_ray = A.n_axes && st_kind(S.st) != kIdle && cylinder_special_case(A.axes, A.n_axes, S.d);  // (looked at once a round)
+    bool odd_ray;
+    if constexpr (kRegroup) odd_ray = st_kind(S.st) != kIdle && ray_special_case(A.axes, A.n_axes, A.n_cone_forms, S.d);
+    else odd_ray = st_kind(S.st) != kIdle && (S.st & kStOdd) != 0;
     Hit h = intersect_first(leaves, prog, pc0, A.n_leaves, st_kind(S.st) != kIdle && !odd_ray, S.o, S.d, (double)S.t_stop, evD, evM, lens, dg);
     if (odd_ray) h.redo = true;
     if constexpr (kShared) {
@@ -1571,7 +1619,9 @@ std::string dev_copy_rows_to_host(int worker, int device, void* image, const voi
   // Large transfers are cut into ranges of whole units, each with a thread and a staging ring of its own: one
   // thread copies out of page-locked memory at 10 to 30 GB/s, the DMA engines deliver more than 50.
   const size_t n_units = (total + unit - 1) / unit;
-  size_t n_threads = total >= (32u << 20) ? kCopyThreads : 1;
+  // (from 8 MB on: the 24.9 MB of a 4K frame took 0.93 ms through one thread, as long as its memcpy alone)
+  static const size_t many_from = [] { const char* e = std::getenv("GMLRT_COPY_THREADS_FROM_MB"); return (size_t)(e ? std::atoi(e) : 8) << 20; }();  // tuning runs
+  size_t n_threads = total >= many_from ? kCopyThreads : 1;
   if (n_threads > n_units) n_threads = n_units;
   auto copy_range = [&](HostStage* hs, size_t unit_begin, size_t unit_end) -> std::string {
     // (calls for one device share its stages: two callers in the same slots would interleave their chunks)
@@ -1837,7 +1887,12 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     const gmlrt_leaf* L = (const gmlrt_leaf*)((const uint8_t*)blob + H.off_leaves);
     std::vector<double> axes;
     for (uint32_t i = 0; i < H.n_leaves; i++) {
-      if (L[i].type != GMLRT_CYLINDER) continue;
+      // (a cone joins with the planes across its axis only: a ray that runs within its base plane, or within rounding
+      // of it, gets the crossing of that plane, (1 - py) / dy, as the quotient of two rounding errors whenever the
+      // height test of primitives.rs:820-827 keeps one of the two mantle crossings and not the other, which rounding
+      // decides; the interval the reference then reports can reach far beyond the solid.  Found by the lattice fuzz: a
+      // bounce ray in the plane x = 0, the base plane of a cone on its side.)
+      if (L[i].type != GMLRT_CYLINDER && L[i].type != GMLRT_CONE) continue;
       // object direction u and world direction d of one ray: d = M u up to scale.  In the parallel case the part of u
       // across the axis is at most 4.5e-4 of the part along it, so d lies within asin(rho) of M e_y with
       // rho = |M|_F * 4.5e-4 / (|M e_y| - |M|_F * 4.5e-4); in the orthogonal case u's part along the axis is at most
@@ -1872,11 +1927,34 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
         }
         axes.insert(axes.end(), {v[0], v[1], v[2], h_, l_, 0.0, 0.0, 0.0});
       };
-      add(ax, hi, -1.0);   // parallel to the axis
+      if (L[i].type == GMLRT_CYLINDER) add(ax, hi, -1.0);   // parallel to the axis
       add(nn, 2.0, lo);    // across it: orthogonal to the normal of the cap planes
     }
     out->n_axes = (uint32_t)(axes.size() / kAxisWords);
+    // The cones' forms (see cone_special_case), one per distinct shape and orientation.
+    out->n_cone_forms = 0;
+    for (uint32_t i = 0; i < H.n_leaves; i++) {
+      if (L[i].type != GMLRT_CONE) continue;
+      double M[3][3], Q[3][3], tr = 0.0;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r][c] = L[i].inv_m[r * 4 + c];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          Q[a][b] = M[0][a] * M[0][b] - M[1][a] * M[1][b] + M[2][a] * M[2][b];  // (M^T J M)
+          if (a == b) tr += M[0][a] * M[0][a] + M[1][a] * M[1][a] + M[2][a] * M[2][a];
+        }
+      double f[kAxisWords] = {Q[0][0] / tr, Q[1][1] / tr, Q[2][2] / tr, 2.0 * Q[0][1] / tr, 2.0 * Q[0][2] / tr, 2.0 * Q[1][2] / tr, kConeFormBound, 0.0};
+      bool finite = tr > 0.0;
+      for (int k = 0; k < 6; k++) finite = finite && std::isfinite(f[k]);
+      if (!finite) { for (int k = 0; k < 6; k++) f[k] = 0.0; }  // (a degenerate transform: every ray takes the exact path)
+      bool have = false;
+      for (size_t k = (size_t)out->n_axes * kAxisWords; k < axes.size() && !have; k += kAxisWords) {
+        have = true;
+        for (int q = 0; q < 6; q++) have = have && std::fabs(axes[k + (size_t)q] - f[q]) <= 1e-12;
+      }
+      if (!have) { axes.insert(axes.end(), f, f + kAxisWords); out->n_cone_forms++; }
+    }
     out->d_axes = nullptr;
+    out->h_axes = axes;
     if (!axes.empty()) {
       HIP_TRY(hipMalloc(&out->d_axes, axes.size() * sizeof(double)));
       HIP_TRY(hipMemcpy(out->d_axes, axes.data(), axes.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -2010,6 +2088,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.max_stack = s->max_stack;
   A.axes = (const double*)s->d_axes;
   A.n_axes = s->n_axes;
+  A.n_cone_forms = s->n_cone_forms;
   for (int i = 0; i < 3; i++) A.amb[i] = p.amb[i];
   // raytracer.rs:131-136
   const double w_world = 2.0 * std::tan(0.5 * (p.fov_deg * (3.14159265358979323846 / 180.0)));
@@ -2350,6 +2429,17 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
   SA.ctx = A.ctx;
   SA.c_x = A.c_x; SA.c_y = A.c_y; SA.pw = A.pw;
+  SA.axes = A.axes; SA.n_axes = A.n_axes; SA.n_cone_forms = A.n_cone_forms;
+  for (uint32_t k = 0; k < kOddInline; k++) {
+    const bool ha = k < s->n_axes && s->h_axes.size() >= (size_t)(k + 1) * kAxisWords;
+    const double* a = ha ? s->h_axes.data() + (size_t)k * kAxisWords : nullptr;
+    SA.odd_axis[k][0] = ha ? a[0] : 0.0; SA.odd_axis[k][1] = ha ? a[1] : 0.0; SA.odd_axis[k][2] = ha ? a[2] : 0.0;
+    SA.odd_axis[k][3] = ha ? a[3] : 2.0;   // (no cosine reaches 2, none is below -1)
+    SA.odd_axis_lo[k] = ha ? a[4] : -1.0;
+    const bool hf = k < s->n_cone_forms && s->h_axes.size() >= (size_t)(s->n_axes + k + 1) * kAxisWords;
+    const double* f = hf ? s->h_axes.data() + (size_t)(s->n_axes + k) * kAxisWords : nullptr;
+    for (int q = 0; q < 6; q++) SA.odd_form[k][q] = hf ? f[q] : (q < 3 ? 1.0 : 0.0);  // (the unit form: 1 for every unit direction)
+  }
   SA.w = A.w; SA.tile_rows = A.tile_rows; SA.part = A.part; SA.nparts = A.nparts; SA.band_row0 = A.band_row0;
   SA.vm_lds_off = A.vm_lds_off;
   SA.parked = levels ? (double*)s->d_parked : nullptr;

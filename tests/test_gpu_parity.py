@@ -282,6 +282,36 @@ def test_sampled_hand_out_of_a_frame_rendered_once(gmlrt, oracle, monkeypatch, n
         assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.hits) == (st_ref.rays_primary, st_ref.rays_shadow, st_ref.rays_reflect, st_ref.hits)
 
 
+def test_cone_ray_along_the_mantle_is_traced_without_bounds(gmlrt, oracle):
+    # A ray parallel to a generator of a cone (here: shadow rays towards a light at 45 degrees over a cone lying on its
+    # side, lattice scene 84456 of the fuzz) makes the reference's quadratic lose its leading coefficient: the "root" is
+    # the quotient of two rounding errors, and when it lands between the apex and the base the reference adds the
+    # crossing of the base plane as the second event, a hit far outside the solid (primitives.rs:778-792, 844-848).
+    # Every bound around the cone culls that hit; the kernel must flag such rays and trace them exactly, without bounds.
+    import random_scenes
+    text = random_scenes.scene_text(84456, 161, 121, 4, lattice=True)
+    img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    assert (img == ref).all(), int((img != ref).any(-1).sum())
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    # the pixel the fuzz found: all three lights are behind the cone's phantom hit, ambient light only
+    assert abs(ref64[78, 152, 1] - 0.07039184187249851) < 1e-15 and ref64[78, 152, 0] == 0.0
+
+
+def test_cone_ray_within_the_base_plane_is_traced_without_bounds(gmlrt, oracle):
+    # lattice scene 233267 of the fuzz: the centre column's bounce rays run in the plane x = 0, which is the base plane of a
+    # cone lying on its side.  Rounding decides which mantle crossing passes the height test, the reference then adds the
+    # crossing of the base plane, (1 - py) / dy with both tiny, and reports an interval that reaches beyond the cone
+    # (primitives.rs:820-848); intersected with a cylinder behind the cone that gives a hit where no cone is.
+    import random_scenes
+    text = random_scenes.scene_text(233267, 161, 121, 4, lattice=True)
+    img, f64, st = gmlrt.render(gmlrt.Program(text=text).calls[0], want_f64=True)
+    ref, ref64, cnt = oracle.OracleProgram(text=text).render(0, want_f64=True, threads=8)
+    assert (img == ref).all(), int((img != ref).any(-1).sum())
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert abs(ref64[108, 80, 1] - 1.2082897458533268) < 1e-12
+
+
 def test_repeated_render_is_deterministic(gmlrt):
     prog = gmlrt.Program(path=os.path.join(SCENES, "cone-fractal.gml"))
     a, _, sa = gmlrt.render(prog.calls[0])
