@@ -111,6 +111,7 @@ struct DeviceScene {
   int order_state = 0;
   int order_way = 0;            // the fastest of them (a trial has to beat way 0 by 2 %)
   float order_ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // kernel time of the launch that ran each way (0: not tried)
+  int order_trials = 0;         // launches the way on trial has had (ways 3 and 4 get two: see where they are timed)
   void* d_tile_batch_img = nullptr;      // way 2's batch table
   uint32_t n_batches_img = 0;
   void* d_tile_order_rest = nullptr;     // way 3: order and batch table of the tiles that are not shared, and the shared ones

@@ -912,7 +912,13 @@ struct Flattener : gml::TreeVisitor {
         // over 10^4 object units and a parallel ray's sideways drift (4.5e-4 per unit) over two.
         lo[0] = lo[2] = -1.001; hi[0] = hi[2] = 1.001; lo[1] = -0.001; hi[1] = 1.001;
         break;
-      case gml::PrimType::Cone: lo[1] = 0.0; break;
+      case gml::PrimType::Cone:
+        // The small root of the reference's quadratic, (-b + sqrt(b^2 - 4ac)) / 2a, cancels when the ray runs nearly
+        // along the mantle (a small).  Rays with |a| <= 1e-8 are traced without bounds (gmlrt_kernels.hip:
+        // cone_special_case); above that the root is off by at most 2^-52 * 2|b| / 2e-8 = 2.2e-8 |b|, |b| <= 2 |origin|
+        // in object space: a thousandth of the unit cone, as for the cylinder, covers origins 2e4 object units away.
+        lo[0] = lo[2] = -1.001; hi[0] = hi[2] = 1.001; lo[1] = -0.001; hi[1] = 1.001;
+        break;
       default: return plane_bound(t);  // half-space: at best bounded on one side of one axis
     }
     const double (*M)[4] = t.m.m;

@@ -6,7 +6,8 @@ import random
 def scene_text(seed, width=64, height=48, depth=2, lattice=False):
     """lattice: positions, sizes and angles come from a coarse grid (halves, right angles), so that faces of
     different primitives coincide exactly, rays run along axes and spans of zero length appear: the cases in which
-    the order of equal distances and the 1e-10 rule of the CSG sweep decide the picture."""
+    the order of equal distances and the 1e-10 rule of the CSG sweep decide the picture.  lattice=2: the same with
+    rotations by eighths of a turn too."""
     rng = random.Random(seed)
     if lattice:
         f = lambda lo, hi: "%.1f" % (round(rng.uniform(lo, hi) * 2.0) / 2.0 or (0.5 if lo > 0 else 0.0))
@@ -32,7 +33,10 @@ def scene_text(seed, width=64, height=48, depth=2, lattice=False):
             elif op == "translate":
                 parts.append("%s %s %s translate" % (f(-0.6, 0.6), f(-0.6, 0.6), f(-0.6, 0.6)))
             else:
-                parts.append("%s %s" % (rng.choice(["0.0", "90.0", "180.0", "-90.0"] + ([] if lattice else [f(-180, 180)])), op))
+                angles = ["0.0", "90.0", "180.0", "-90.0"]
+                if lattice == 2:  # eighths of a turn as well: rays along a cone's mantle, along the diagonals of cubes
+                    angles += ["45.0", "-45.0", "135.0"]
+                parts.append("%s %s" % (rng.choice(angles + ([] if lattice else [f(-180, 180)])), op))
         parts.append("%s %s %s translate" % (f(-1.5, 1.5), f(-1.0, 1.0), f(2.5, 5.0)))
         return " ".join(parts)
 

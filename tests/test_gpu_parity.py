@@ -604,6 +604,28 @@ def test_random_scenes_match_oracle(gmlrt, oracle, first, lattice):
         assert np.abs(f64[both] - ref64[both]).max() <= 1e-9, seed
 
 
+@pytest.mark.parametrize("lattice", [False, True])
+def test_every_ray_by_the_full_list_algorithm(gmlrt, oracle, monkeypatch, lattice):
+    # The kernel's second tracer (every operator of the tree evaluated with full lists, no bounds: the path of the rays
+    # in the reference's special cases and of the 1e-10 slivers under the root) normally sees one ray in 10^5.  Here
+    # every ray of forty random scenes, of the chess scene (261 leaves: leaves marked beforehand, subtrees without a
+    # marked leaf jumped over) and of a scene below the size at which leaves are marked goes through it.
+    import random_scenes
+    monkeypatch.setenv("GMLRT_ALL_RAYS_WITHOUT_BOUNDS", "1")
+    texts = [random_scenes.scene_text(seed, 65, 49, 3, lattice=lattice) for seed in range(300, 340)]
+    if not lattice:
+        texts += [open(os.path.join(SCENES, n + ".gml")).read() for n in ("snowgoon", "dice", "golf")]
+    calls = [(gmlrt.Program(text=t).calls[0], oracle.OracleProgram(text=t), 0) for t in texts]
+    if not lattice:
+        chess = os.path.join(SCENES, "chess.gml")
+        calls.append((gmlrt.Program(path=chess).calls[0].with_overrides(240, 135, 3), oracle.OracleProgram(path=chess), (240, 135, 3)))
+    for k, (call, orc, over) in enumerate(calls):
+        img, _, st = gmlrt.render(call)
+        ref, _, cnt = orc.render(0, threads=8) if over == 0 else orc.render(0, w=over[0], h=over[1], depth=over[2], threads=8)
+        assert (img != ref).sum() == 0, k
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect) == (cnt["primary"], cnt["shadow"], cnt["reflect"]), k
+
+
 # The reference's other scene files (its gml/ directory): every `render` each program executes, at the
 # size and depth the file names.  They exercise what the seven configuration scenes do not: array `get`
 # inside surface functions (checked-cube, cube), closures as values (holes), clampf/frac (golf), several

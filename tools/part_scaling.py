@@ -19,7 +19,7 @@ for n in (1, 2, 4, 8):
         ctypes.memmove(ctypes.byref(p), ctypes.byref(call.params), ctypes.sizeof(p))
         p.tile_rows, p.part, p.nparts = 8, part, n
         out = torch.zeros((rowtiles.padded_rows(2160, 8, n), 3840, 3), dtype=torch.uint8, device="cuda:0")
-        for _ in range(5):  # one launch that times the tiles, three ways of handing them out on trial, one decided
+        for _ in range(6):  # one launch that times the tiles, three ways of handing them out on trial (the third twice), one decided
             scene.render_into(p, out.data_ptr())
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """One seeded random scene (tests/random_scenes.py) on the GPU against the CPU oracle: the differing pixels, their
-values on both sides and the ray counts.  Usage on the GPU box: python tools/seed_check.py <seed> [lattice|plain] [w h depth]"""
+values on both sides and the ray counts.  Usage on the GPU box: python tools/seed_check.py <seed> [lattice|lattice45|plain] [w h depth]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for d in ("tests", "oracle", "rust-raytracer_amd"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import torch, numpy as np, random_scenes, oracle_py, gmlrt
 seed = int(sys.argv[1])
-lattice = len(sys.argv) > 2 and sys.argv[2] == "lattice"
+lattice = (2 if sys.argv[2] == "lattice45" else sys.argv[2] == "lattice") if len(sys.argv) > 2 else False
 w, h, depth = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (161 if lattice else 160, 121 if lattice else 120, 4)
 t = random_scenes.scene_text(seed, w, h, depth, lattice=lattice)
 if os.environ.get("SEED_CHECK_TEXT"):
