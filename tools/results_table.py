@@ -16,8 +16,11 @@ CONFIGS = [("spheres", 640, 480, None), ("spheres", 3840, 2160, None), ("chess",
            ("cone-fractal", 3840, 2160, None), ("spotlight", 3840, 2160, None), ("house", 3840, 2160, None),
            ("large", 7680, 4320, 8)]
 THREADS = min(16, os.cpu_count() or 1)
-print("| config | GPUs | rays | kernel ms | Mrays/s | %% FP32 peak (algorithmic) | CPU 1-thread Mrays/s | CPU %d-thread Mrays/s | rows compared | pixels within 1/255 | max abs diff |" % THREADS)
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+# executed f64 flops, active lanes and memory-side traffic per launch come from the committed counter summaries
+# (profiles/r03_<scene>_pmc_summary.json, replayed by bench.measured_counters only for the same workload and the same
+# kernel sources) and are divided by the kernel time measured here
+print("| config | GPUs | rays | kernel ms | Mrays/s | executed f64 TFLOP/s | frac of FP64 peak | lanes active per VALU instr. | traffic GB/launch | %% FP32 peak (algorithmic) | CPU 1-thread Mrays/s | CPU %d-thread Mrays/s | rows compared | pixels within 1/255 | max abs diff |" % THREADS)
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, w, h, depth in CONFIGS:
     path = os.path.join(ROOT, "scenes", name + ".gml")
     call = gmlrt.Program(path=path).calls[0].with_overrides(w, h, depth)
@@ -25,7 +28,7 @@ for name, w, h, depth in CONFIGS:
     flops_per_ray, _ = bench.scene_flops_per_ray(call.blob)
     scene = gmlrt.DeviceScene(call.blob, 0)
     out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
-    for _ in range(12):  # three launches learn the tile hand-out, the rest warm the clocks
+    for _ in range(12):  # up to six launches learn the tile hand-out, the rest warm the clocks
         scene.render_into(call.params, out.data_ptr())
     sts = [scene.render_into(call.params, out.data_ptr()) for _ in range(5)]
     ms = sum(s.kernel_ms for s in sts) / len(sts)
@@ -43,6 +46,13 @@ for name, w, h, depth in CONFIGS:
     t1 = time.time() - t0
     d = np.abs(img[rows].astype(np.int16) - ref.astype(np.int16)).max(axis=-1)
     tflops = (st.rays * flops_per_ray + st.hits * bench.F_SHADE) / (ms * 1e-3) / 1e12
-    print("| %s %dx%d depth %d | 1 | %d | %.3f | %.0f | %.1f | %.3f | %.2f | %d | %.4f %% | %d |" % (
-        name, w, h, depth, st.rays, ms, st.rays / ms / 1e3, 100.0 * tflops / bench.PEAK_FP32_VALU_TFLOPS,
+    pmc, _ = bench.measured_counters("%s.gml %dx%d depth %d" % (name, w, h, depth))
+    if pmc:
+        ex = pmc["f64_flops_per_launch"] / (ms * 1e-3) / 1e12
+        roof = "%.2f | %.3f | %.1f | %.2f" % (ex, ex / bench.PEAK_FP64_VALU_TFLOPS, pmc["mean_active_lanes_per_valu_instruction"],
+                                              (pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]) / 1e9)
+    else:
+        roof = "- | - | - | -"
+    print("| %s %dx%d depth %d | 1 | %d | %.3f | %.0f | %s | %.1f | %.3f | %.2f | %d | %.4f %% | %d |" % (
+        name, w, h, depth, st.rays, ms, st.rays / ms / 1e3, roof, 100.0 * tflops / bench.PEAK_FP32_VALU_TFLOPS,
         sum(c1.values()) / t1 / 1e6, sum(cn.values()) / tn / 1e6, len(rows), 100.0 * (d <= 1).mean(), int(d.max())), flush=True)
