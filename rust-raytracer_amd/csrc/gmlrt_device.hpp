@@ -183,4 +183,17 @@ std::string band_pipe_wait(BandPipe* bp, int slot, const double** host);
 // Frees what dev_scene_destroy keeps for the next scene on the same device (scratch buffers, events).
 void dev_release_cached(void);
 
+// Directions of rays for which the reference's cylinder and cone leave geometry (primitives.rs:644-663, 778-792,
+// 844-858) and report hits outside the solid: such rays must meet no bound.  kAxisWords doubles a class.  An axis
+// class: unit vector x y z, the cosine at or above which a unit direction counts as parallel to it, the cosine at or
+// below which as orthogonal (a value no cosine reaches switches a test off).  A cone form: q00 q11 q22 2q01 2q02 2q12 of
+// the symmetric form Q = M^T diag(1, -1, 1) M / trace(M^T M) (M: the linear part of the cone's inverse transform),
+// then the bound: a unit direction d with |d^T Q d| <= bound counts as running along the mantle.
+constexpr uint32_t kAxisWords = 8;
+#ifndef GMLRT_CONE_FORM_BOUND
+#define GMLRT_CONE_FORM_BOUND 1e-8
+#endif
+constexpr double kConeFormBound = GMLRT_CONE_FORM_BOUND;
+void special_ray_classes(const void* blob, std::vector<double>* classes, uint32_t* n_axes, uint32_t* n_cone_forms);
+
 }  // namespace gmlrt

@@ -97,7 +97,6 @@ enum RayKind : int { kIdle = 0, kView = 1, kShadow = 2 };
 // margins: a flagged ray only takes the slower exact path); the kernel flags a lane whose ray matches a class, keeps
 // it out of the bounded traversal and traces it with the full-list algorithm without bounds.  About one ray in 10^6
 // per class.  kAxisWords doubles a class: axis x y z, cosine above which "parallel", cosine below which "orthogonal".
-constexpr uint32_t kAxisWords = 8;
 __device__ inline bool cylinder_special_case(const double* __restrict__ axes, uint32_t n_axes, V3 d) {
   bool odd = false;
   for (uint32_t k = 0; k < n_axes; k++) {
@@ -141,14 +140,7 @@ __device__ inline bool ray_special_case(const double* __restrict__ axes, uint32_
   return (n_axes && cylinder_special_case(axes, n_axes, d)) || (n_forms && cone_special_case(axes + (size_t)n_axes * kAxisWords, n_forms, d));
 }
 constexpr uint32_t kOddInline = 4;
-#ifndef GMLRT_CONE_FORM_BOUND
-#define GMLRT_CONE_FORM_BOUND 1e-8
-#endif
-constexpr double kConeFormBound = GMLRT_CONE_FORM_BOUND;
 constexpr uint32_t kStOdd = 1u << 24;  // (not in the kernel that regroups the rays of a block, where bits 31..24 name the ray's context slot)
-__device__ __noinline__ uint32_t ray_special_bit(const double* __restrict__ axes, uint32_t n_axes, uint32_t n_forms, double dx, double dy, double dz) {
-  return ray_special_case(axes, n_axes, n_forms, V3{dx, dy, dz}) ? kStOdd : 0u;
-}
 
 // Read-only scene sections.  Passed to the kernel as separate `const __restrict__`
 // parameters so that wave-uniform reads of them become scalar loads.
@@ -357,6 +349,40 @@ __device__ inline T* wave_uniform(T* p) {
   const uint64_t v = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return (T*)(((uint64_t)hi << 32) | lo);
+}
+
+// ray_special_case for a new ray, asked of the launch record: the first kOddInline classes of each kind lie inline in
+// it and arrive in one round of scalar loads; what a scene has beyond them comes through the list.
+__device__ inline bool ray_special_inline(const ShadeArgs* __restrict__ SA, V3 d) {
+  const uint32_t na = SA->n_axes, nf = SA->n_cone_forms;
+  bool odd = false;
+  if (na) {
+#pragma unroll
+    for (uint32_t k = 0; k < kOddInline; k++) {
+      if (k >= na) break;
+      const double c = fabs(__builtin_fma(d.x, SA->odd_axis[k][0], __builtin_fma(d.y, SA->odd_axis[k][1], d.z * SA->odd_axis[k][2])));
+      odd |= (c >= SA->odd_axis[k][3]) | (c <= SA->odd_axis_lo[k]);
+    }
+    if (na > kOddInline) odd |= cylinder_special_case(const_space(wave_uniform(SA->axes)) + (size_t)kOddInline * kAxisWords, na - kOddInline, d);
+  }
+  if (nf) {
+    const double xx = d.x * d.x, yy = d.y * d.y, zz = d.z * d.z, xy = d.x * d.y, xz = d.x * d.z, yz = d.y * d.z;
+#pragma unroll
+    for (uint32_t k = 0; k < kOddInline; k++) {
+      if (k >= nf) break;
+      const double* __restrict__ f = SA->odd_form[k];
+      const double q = __builtin_fma(f[0], xx, __builtin_fma(f[1], yy, __builtin_fma(f[2], zz, __builtin_fma(f[3], xy, __builtin_fma(f[4], xz, f[5] * yz)))));
+      odd |= !(fabs(q) > kConeFormBound);
+    }
+    if (nf > kOddInline) odd |= cone_special_case(const_space(wave_uniform(SA->axes)) + (size_t)(na + kOddInline) * kAxisWords, nf - kOddInline, d);
+  }
+  return odd;
+}
+// (out of line: for the rays that are not made by the per-ray code, i.e. camera rays and rays taken from a queue.  Asked
+// of the class list in device memory instead of the launch record, a load after a load for every class, the camera rays'
+// flags cost the chess frame 1.2 %; this way 0.4 %.)
+__device__ __noinline__ uint32_t ray_special_bit(const ShadeArgs* __restrict__ sa_v, double dx, double dy, double dz) {
+  return ray_special_inline(const_space(wave_uniform(sa_v)), V3{dx, dy, dz}) ? kStOdd : 0u;
 }
 
 // ---------------------------------------------------------------- CSG traversal
@@ -974,7 +1000,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
       S.d = vnormalize(dir);                                                                                       \
       S.t_stop = -__builtin_inff();                                                                                \
       S.st = kView | (kRegroup ? S.st & 0xFF000000u                                                                \
-                               : (A.n_axes | A.n_cone_forms) ? ray_special_bit(A.axes, A.n_axes, A.n_cone_forms, S.d.x, S.d.y, S.d.z) : 0u); /* level 0 */ \
+                               : (A.n_axes | A.n_cone_forms) ? ray_special_bit(shade_args, S.d.x, S.d.y, S.d.z) : 0u); /* level 0 */           \
       S.pix = yl * (uint32_t)A.w + x;                                                                              \
     }                                                                                                              \
   } while (0)
@@ -1350,7 +1376,7 @@ __global__ __launch_bounds__(kBlock, GMLRT_WAVES_PER_SIMD) void render_kernel(
             S.d = {r1.y, r2.x, r2.y};
             S.pix = (uint32_t)__builtin_bit_cast(uint64_t, r3.x);
             S.t_stop = -__builtin_inff();
-            S.st = kView | (A.level << 2) | ((A.n_axes | A.n_cone_forms) ? ray_special_bit(A.axes, A.n_axes, A.n_cone_forms, S.d.x, S.d.y, S.d.z) : 0u);
+            S.st = kView | (A.level << 2) | ((A.n_axes | A.n_cone_forms) ? ray_special_bit(shade_args, S.d.x, S.d.y, S.d.z) : 0u);
           }
         } else {
           GMLRT_CAMERA_RAY(cur_tile, (tile_base + rank) & 63u);
@@ -2061,88 +2087,10 @@ std::string dev_scene_create(const void* blob, size_t bytes, int device, DeviceS
     }
   }
   {
-    // The cylinders' axes in world space, one class per distinct direction (see cylinder_special_case).
-    const gmlrt_blob_header& H = out->hdr;
-    const gmlrt_leaf* L = (const gmlrt_leaf*)((const uint8_t*)blob + H.off_leaves);
+    // The classes of rays that must meet no bound (see cylinder_special_case, cone_special_case): made on the host
+    // from the leaves' transforms (gmlrt_scene.cpp: special_ray_classes).
     std::vector<double> axes;
-    for (uint32_t i = 0; i < H.n_leaves; i++) {
-      // (a cone joins with the planes across its axis only: a ray that runs within its base plane, or within rounding
-      // of it, gets the crossing of that plane, (1 - py) / dy, as the quotient of two rounding errors whenever the
-      // height test of primitives.rs:820-827 keeps one of the two mantle crossings and not the other, which rounding
-      // decides; the interval the reference then reports can reach far beyond the solid.  Found by the lattice fuzz: a
-      // bounce ray in the plane x = 0, the base plane of a cone on its side.)
-      if (L[i].type != GMLRT_CYLINDER && L[i].type != GMLRT_CONE) continue;
-      // object direction u and world direction d of one ray: d = M u up to scale.  In the parallel case the part of u
-      // across the axis is at most 4.473e-4 of |u| (1 - (1 - 1e-7)^2 = 2e-7), so d lies within asin(rho) of M e_y with
-      // rho = |M|_2 * 4.473e-4 / (|M e_y| - |M|_2 * 4.473e-4); in the orthogonal case u's part along the axis is at most
-      // 1e-7 of |u| = |A d| <= |A|_2 (A = the inverse's linear part), so |d . n| <= 1e-7 * |A|_2 / |A^T e_y| for the
-      // unit normal n = A^T e_y / |A^T e_y| of the planes across the axis.  Axis and normal are classes of their own
-      // (they differ for a sheared cylinder).  Margins of 2 %: the directions are compared in doubles, and every
-      // flagged ray costs its wave a walk through the whole tree.
-      double ax[3], nn[3];
-      for (int r = 0; r < 3; r++) {
-        ax[r] = L[i].m[r * 4 + 1];
-        nn[r] = L[i].inv_m[4 + r];
-      }
-      // (the largest stretch of a 3 x 4 transform's linear part: sqrt(lambda_max(T^T T)) <= the square root of the
-      // largest absolute row sum of T^T T, with equality for rotations, scalings along the axes and their products)
-      auto stretch = [](const double* T) {
-        double top = 0.0;
-        for (int a = 0; a < 3; a++) {
-          double row = 0.0;
-          for (int b = 0; b < 3; b++) row += std::fabs(T[a] * T[b] + T[4 + a] * T[4 + b] + T[8 + a] * T[8 + b]);
-          top = std::max(top, row);
-        }
-        return std::sqrt(top);
-      };
-      const double fm = stretch(L[i].m), fa = stretch(L[i].inv_m);
-      const double la = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), ln = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-      double hi = -1.0, lo = 2.0;  // (a degenerate transform: every ray takes the exact path)
-      if (la > 0.0 && ln > 0.0 && std::isfinite(fm) && std::isfinite(fa)) {
-        const double spread = fm * 4.48e-4 * 1.02;
-        const double rho = la > spread ? spread / (la - spread) : 1.0;
-        hi = rho < 1.0 ? std::sqrt(1.0 - rho * rho) : -1.0;
-        lo = 1e-7 * fa * 1.02 / ln;  // bound on |d . n| for n of unit length: |(A d)_y| < 1e-7 |A d| <= 1e-7 |A|_2
-        if (!(lo < 1.0)) lo = 2.0;
-        for (int r = 0; r < 3; r++) { ax[r] /= la; nn[r] /= ln; }
-      }
-      auto add = [&](const double v[3], double h_, double l_) {
-        for (size_t k = 0; k < axes.size(); k += kAxisWords) {
-          const double dot = std::fabs(axes[k] * v[0] + axes[k + 1] * v[1] + axes[k + 2] * v[2]);
-          if (dot >= 1.0 - 1e-12) {  // the same direction: one class, the wider margins
-            axes[k + 3] = std::min(axes[k + 3], h_);
-            axes[k + 4] = std::max(axes[k + 4], l_);
-            return;
-          }
-        }
-        axes.insert(axes.end(), {v[0], v[1], v[2], h_, l_, 0.0, 0.0, 0.0});
-      };
-      if (L[i].type == GMLRT_CYLINDER) add(ax, hi, -1.0);   // parallel to the axis
-      add(nn, 2.0, lo);    // across it: orthogonal to the normal of the cap planes
-    }
-    out->n_axes = (uint32_t)(axes.size() / kAxisWords);
-    // The cones' forms (see cone_special_case), one per distinct shape and orientation.
-    out->n_cone_forms = 0;
-    for (uint32_t i = 0; i < H.n_leaves; i++) {
-      if (L[i].type != GMLRT_CONE) continue;
-      double M[3][3], Q[3][3], tr = 0.0;
-      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r][c] = L[i].inv_m[r * 4 + c];
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-          Q[a][b] = M[0][a] * M[0][b] - M[1][a] * M[1][b] + M[2][a] * M[2][b];  // (M^T J M)
-          if (a == b) tr += M[0][a] * M[0][a] + M[1][a] * M[1][a] + M[2][a] * M[2][a];
-        }
-      double f[kAxisWords] = {Q[0][0] / tr, Q[1][1] / tr, Q[2][2] / tr, 2.0 * Q[0][1] / tr, 2.0 * Q[0][2] / tr, 2.0 * Q[1][2] / tr, kConeFormBound, 0.0};
-      bool finite = tr > 0.0;
-      for (int k = 0; k < 6; k++) finite = finite && std::isfinite(f[k]);
-      if (!finite) { for (int k = 0; k < 6; k++) f[k] = 0.0; }  // (a degenerate transform: every ray takes the exact path)
-      bool have = false;
-      for (size_t k = (size_t)out->n_axes * kAxisWords; k < axes.size() && !have; k += kAxisWords) {
-        have = true;
-        for (int q = 0; q < 6; q++) have = have && std::fabs(axes[k + (size_t)q] - f[q]) <= 1e-12;
-      }
-      if (!have) { axes.insert(axes.end(), f, f + kAxisWords); out->n_cone_forms++; }
-    }
+    special_ray_classes(blob, &axes, &out->n_axes, &out->n_cone_forms);
     if (std::getenv("GMLRT_NO_SPECIAL_CASES")) { axes.clear(); out->n_axes = out->n_cone_forms = 0; }  // tuning runs: what the flags cost
     if (const char* e = std::getenv("GMLRT_ALL_RAYS_WITHOUT_BOUNDS"); e && *e == '1') {
       // tests: a class that every direction belongs to, so that every ray is traced by the full-list algorithm

@@ -8,6 +8,7 @@
 #include <map>
 #include <tuple>
 
+#include "gmlrt_device.hpp"
 #include "gmlrt_surface_vm.h"
 
 namespace gmlrt {
@@ -1238,6 +1239,95 @@ std::string validate_blob(const void* blob, size_t bytes) {
     if (!ended) return "surface code runs off the end of the section";
   }
   return "";
+}
+
+// The classes of ray directions that the kernel traces without bounds (gmlrt_kernels.hip: cylinder_special_case,
+// cone_special_case; layout of a class there and at kAxisWords).  First the cylinders' axes and the normals of the
+// cylinders' and cones' cap planes in world space, one class per distinct direction, then one quadratic form per distinct
+// cone shape and orientation.
+void special_ray_classes(const void* blob, std::vector<double>* classes, uint32_t* n_axes, uint32_t* n_cone_forms) {
+  const gmlrt_blob_header& H = *(const gmlrt_blob_header*)blob;
+  const gmlrt_leaf* L = (const gmlrt_leaf*)((const uint8_t*)blob + H.off_leaves);
+  std::vector<double>& axes = *classes;
+  axes.clear();
+  for (uint32_t i = 0; i < H.n_leaves; i++) {
+    // (a cone joins with the planes across its axis only: a ray that runs within its base plane, or within rounding
+    // of it, gets the crossing of that plane, (1 - py) / dy, as the quotient of two rounding errors whenever the
+    // height test of primitives.rs:820-827 keeps one of the two mantle crossings and not the other, which rounding
+    // decides; the interval the reference then reports can reach far beyond the solid.  Found by the lattice fuzz: a
+    // bounce ray in the plane x = 0, the base plane of a cone on its side.)
+    if (L[i].type != GMLRT_CYLINDER && L[i].type != GMLRT_CONE) continue;
+    // object direction u and world direction d of one ray: d = M u up to scale.  In the parallel case the part of u
+    // across the axis is at most 4.473e-4 of |u| (1 - (1 - 1e-7)^2 = 2e-7), so d lies within asin(rho) of M e_y with
+    // rho = |M|_2 * 4.473e-4 / (|M e_y| - |M|_2 * 4.473e-4); in the orthogonal case u's part along the axis is at most
+    // 1e-7 of |u| = |A d| <= |A|_2 (A = the inverse's linear part), so |d . n| <= 1e-7 * |A|_2 / |A^T e_y| for the
+    // unit normal n = A^T e_y / |A^T e_y| of the planes across the axis.  Axis and normal are classes of their own
+    // (they differ for a sheared cylinder).  Margins of 2 %: the directions are compared in doubles, and every
+    // flagged ray costs its wave a walk through the whole tree.
+    double ax[3], nn[3];
+    for (int r = 0; r < 3; r++) {
+      ax[r] = L[i].m[r * 4 + 1];
+      nn[r] = L[i].inv_m[4 + r];
+    }
+    // (the largest stretch of a 3 x 4 transform's linear part: sqrt(lambda_max(T^T T)) <= the square root of the
+    // largest absolute row sum of T^T T, with equality for rotations, scalings along the axes and their products)
+    auto stretch = [](const double* T) {
+      double top = 0.0;
+      for (int a = 0; a < 3; a++) {
+        double row = 0.0;
+        for (int b = 0; b < 3; b++) row += std::fabs(T[a] * T[b] + T[4 + a] * T[4 + b] + T[8 + a] * T[8 + b]);
+        top = std::max(top, row);
+      }
+      return std::sqrt(top);
+    };
+    const double fm = stretch(L[i].m), fa = stretch(L[i].inv_m);
+    const double la = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), ln = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+    double hi = -1.0, lo = 2.0;  // (a degenerate transform: every ray takes the exact path)
+    if (la > 0.0 && ln > 0.0 && std::isfinite(fm) && std::isfinite(fa)) {
+      const double spread = fm * 4.48e-4 * 1.02;
+      const double rho = la > spread ? spread / (la - spread) : 1.0;
+      hi = rho < 1.0 ? std::sqrt(1.0 - rho * rho) : -1.0;
+      lo = 1e-7 * fa * 1.02 / ln;  // bound on |d . n| for n of unit length: |(A d)_y| < 1e-7 |A d| <= 1e-7 |A|_2
+      if (!(lo < 1.0)) lo = 2.0;
+      for (int r = 0; r < 3; r++) { ax[r] /= la; nn[r] /= ln; }
+    }
+    auto add = [&](const double v[3], double h_, double l_) {
+      for (size_t k = 0; k < axes.size(); k += kAxisWords) {
+        const double dot = std::fabs(axes[k] * v[0] + axes[k + 1] * v[1] + axes[k + 2] * v[2]);
+        if (dot >= 1.0 - 1e-12) {  // the same direction: one class, the wider margins
+          axes[k + 3] = std::min(axes[k + 3], h_);
+          axes[k + 4] = std::max(axes[k + 4], l_);
+          return;
+        }
+      }
+      axes.insert(axes.end(), {v[0], v[1], v[2], h_, l_, 0.0, 0.0, 0.0});
+    };
+    if (L[i].type == GMLRT_CYLINDER) add(ax, hi, -1.0);   // parallel to the axis
+    add(nn, 2.0, lo);    // across it: orthogonal to the normal of the cap planes
+  }
+  *n_axes = (uint32_t)(axes.size() / kAxisWords);
+  // The cones' forms (see cone_special_case), one per distinct shape and orientation.
+  *n_cone_forms = 0;
+  for (uint32_t i = 0; i < H.n_leaves; i++) {
+    if (L[i].type != GMLRT_CONE) continue;
+    double M[3][3], Q[3][3], tr = 0.0;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r][c] = L[i].inv_m[r * 4 + c];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        Q[a][b] = M[0][a] * M[0][b] - M[1][a] * M[1][b] + M[2][a] * M[2][b];  // (M^T J M)
+        if (a == b) tr += M[0][a] * M[0][a] + M[1][a] * M[1][a] + M[2][a] * M[2][a];
+      }
+    double f[kAxisWords] = {Q[0][0] / tr, Q[1][1] / tr, Q[2][2] / tr, 2.0 * Q[0][1] / tr, 2.0 * Q[0][2] / tr, 2.0 * Q[1][2] / tr, kConeFormBound, 0.0};
+    bool finite = tr > 0.0;
+    for (int k = 0; k < 6; k++) finite = finite && std::isfinite(f[k]);
+    if (!finite) { for (int k = 0; k < 6; k++) f[k] = 0.0; }  // (a degenerate transform: every ray takes the exact path)
+    bool have = false;
+    for (size_t k = (size_t)*n_axes * kAxisWords; k < axes.size() && !have; k += kAxisWords) {
+      have = true;
+      for (int q = 0; q < 6; q++) have = have && std::fabs(axes[k + (size_t)q] - f[q]) <= 1e-12;
+    }
+    if (!have) { axes.insert(axes.end(), f, f + kAxisWords); (*n_cone_forms)++; }
+  }
 }
 
 }  // namespace gmlrt

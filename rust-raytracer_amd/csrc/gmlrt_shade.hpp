@@ -317,30 +317,8 @@ __device__ GMLRT_AFTER_INLINE LaneState after_traversal(LaneState S, const doubl
   if constexpr (!kSlot) {
     // a new ray: is it one that must be traced exactly, without bounds (ray_special_case)?  The first classes of each
     // kind come out of the launch record, all in one round of scalar loads; what a scene has beyond them, through the list.
-    const uint32_t na = SA->n_axes, nf = SA->n_cone_forms;
-    if (kind != kIdle && (na | nf) != 0u) {
-      const V3 d = S.d;
-      bool odd = false;
-      if (na) {
-#pragma unroll
-        for (uint32_t k = 0; k < kOddInline; k++) {
-          if (k >= na) break;
-          const double c = fabs(__builtin_fma(d.x, SA->odd_axis[k][0], __builtin_fma(d.y, SA->odd_axis[k][1], d.z * SA->odd_axis[k][2])));
-          odd |= (c >= SA->odd_axis[k][3]) | (c <= SA->odd_axis_lo[k]);
-        }
-        if (na > kOddInline) odd |= cylinder_special_case(const_space(wave_uniform(SA->axes)) + (size_t)kOddInline * kAxisWords, na - kOddInline, d);
-      }
-      if (nf) {
-        const double xx = d.x * d.x, yy = d.y * d.y, zz = d.z * d.z, xy = d.x * d.y, xz = d.x * d.z, yz = d.y * d.z;
-#pragma unroll
-        for (uint32_t k = 0; k < kOddInline; k++) {
-          if (k >= nf) break;
-          const double* __restrict__ f = SA->odd_form[k];
-          const double q = __builtin_fma(f[0], xx, __builtin_fma(f[1], yy, __builtin_fma(f[2], zz, __builtin_fma(f[3], xy, __builtin_fma(f[4], xz, f[5] * yz)))));
-          odd |= !(fabs(q) > kConeFormBound);
-        }
-        if (nf > kOddInline) odd |= cone_special_case(const_space(wave_uniform(SA->axes)) + (size_t)(na + kOddInline) * kAxisWords, nf - kOddInline, d);
-      }
+    if (kind != kIdle && (SA->n_axes | SA->n_cone_forms) != 0u) {
+      const bool odd = ray_special_inline(SA, S.d);
       if (odd) S.st |= kStOdd;
     }
   }

@@ -12,6 +12,7 @@
 
 #include "../../rust-raytracer_amd/csrc/gml_front.hpp"
 #include "../../rust-raytracer_amd/csrc/gmlrt_scene.hpp"
+#include "../../rust-raytracer_amd/csrc/gmlrt_device.hpp"
 
 namespace {
 
@@ -303,6 +304,18 @@ unsigned long long th_fnv1a(const unsigned char* p, unsigned long long n) {
   unsigned long long h = 1469598103934665603ull;
   for (unsigned long long i = 0; i < n; i++) h = (h ^ p[i]) * 1099511628211ull;
   return h;
+}
+
+// The classes of ray directions that the kernel traces without bounds, as the host lists them for a scene blob
+// (gmlrt_scene.cpp: special_ray_classes): writes up to cap doubles, returns how many the list has.
+int th_special_ray_classes(const void* blob, double* out, int cap, unsigned* n_axes, unsigned* n_cone_forms) {
+  std::vector<double> c;
+  uint32_t a = 0, f = 0;
+  gmlrt::special_ray_classes(blob, &c, &a, &f);
+  *n_axes = a;
+  *n_cone_forms = f;
+  for (size_t i = 0; i < c.size() && (int)i < cap; i++) out[i] = c[i];
+  return (int)c.size();
 }
 
 }  // extern "C"
