@@ -8,6 +8,10 @@ rows are gathered to rank 0 (the only collective).  Rank 0 prints one JSON line.
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+The other configurations (parity-test cases; a scene's own depth unless --depth is given):
+  python bench.py --scene scenes/fractal.gml                      (likewise cone-fractal, spotlight, house, spheres)
+  python bench.py --gpus 8 --scene scenes/large.gml --width 7680 --height 4320 --depth 8
 """
 import argparse
 import ctypes

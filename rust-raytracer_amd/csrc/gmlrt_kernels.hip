@@ -571,6 +571,23 @@ __device__ inline double readlane_f64(double v, int j) {
 // merged two lists, time of the marking and of the walk (100 MHz clock)
 __device__ unsigned long long g_general_stats[12];
 #endif
+// One primitive's test, and the look before it, for the full-list tracer; out of line.  What the tracer costs the
+// kernel is not its own time (one ray in 10^5 gets there) but its registers: the compiler hands the kernel the exact
+// set of registers the tracer and everything below it overwrite, and the kernel's loop keeps its long-lived values in
+// the rest across the call.  A version of the tracer that also kept one ray's tests of 64 leaves in registers, a leaf
+// per lane (22 more live registers; its walk was a quarter shorter), took registers the loop lives in: ten more
+// values of the loop went to scratch, one of them reloaded inside the traversal, and every frame of every scene was
+// 2.4 % slower.  The kernel's own frame (96 bytes a lane) is the figure to watch when this function changes.
+__device__ __noinline__ PrimHit leaf_test(const gmlrt_leaf* L, V3 o, V3 d, double& scale) {
+  V3 rd, rp;
+  to_object(L->inv_m, o, d, scale, rd, rp);
+  return isect_prim(L->type, rp, rd);
+}
+__device__ __noinline__ bool leaf_look(const gmlrt_leaf* L, V3 o, V3 d) {
+  V3 td, rp;
+  to_object_raw(L->inv_m, o, d, td, rp);
+  return prim_may_enter(L->type, rp, td, vdot(td, td));
+}
 constexpr uint32_t kMarkLeavesFrom = 24;  // scenes with fewer leaves: the walk alone is shorter than the marking
 __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ leaves_v, const uint32_t* __restrict__ nodes_v,
                                               const gmlrt_bound* __restrict__ bounds_v, uint32_t n_nodes,
@@ -618,13 +635,7 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
       const V3 dj = {readlane_f64(d.x, j), readlane_f64(d.y, j), readlane_f64(d.z, j)};
       for (uint32_t w = 0; w * 64u < n_leaves; w++) {
         const uint32_t i = w * 64u + lane;
-        bool may = false;
-        if (i < n_leaves) {
-          const gmlrt_leaf* L = leaves + i;
-          V3 td, rp;
-          to_object_raw(L->inv_m, oj, dj, td, rp);
-          may = prim_may_enter(L->type, rp, td, vdot(td, td));
-        }
+        const bool may = i < n_leaves && leaf_look(leaves + i, oj, dj);
         const uint64_t m = __ballot(may);
         if (lane == w) marks |= m;
       }
@@ -642,18 +653,6 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
     }
   }
   DIAG(const unsigned long long gs_t1 = wall_clock64();)
-  // (a wave that is here for a single ray: nearly always)
-  const unsigned long long active_lanes = __ballot(active);
-  const bool single_ray = marked && __popcll(active_lanes) == 1;
-  V3 ray_o = o, ray_d = d;
-  if (single_ray) {
-    const int j = __builtin_ctzll(active_lanes);
-    ray_o = {readlane_f64(o.x, j), readlane_f64(o.y, j), readlane_f64(o.z, j)};
-    ray_d = {readlane_f64(d.x, j), readlane_f64(d.y, j), readlane_f64(d.z, j)};
-  }
-  PrimHit lot = {0, 0.0, 0.0, 0, 0};  // the tests of leaves 64 lot_at .. 64 lot_at + 63 for that ray, one per lane
-  double lot_scale = 0.0;
-  uint32_t lot_at = 0xFFFFFFFFu;
   // The words of the tree come 64 at a time, one per lane, and are handed to the wave from there: a load per word
   // through the scalar cache waits for the L2 nearly every time (the cache is shared with waves that stream the
   // traversal program through it), half a microsecond a word.
@@ -723,38 +722,7 @@ __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ lea
       DIAG(const unsigned long long gs_l0 = wall_clock64();)
       double scale;
       PrimHit ph;
-      if (single_ray) {
-        // One ray, and it grazes forty leaves of the chess scene: the tests are made 64 leaves at a time, each lane
-        // with a leaf of its own (the same operations on the same numbers as below), and handed to the ray's lane.
-        const uint32_t i = word & 0x3FFFFFFFu;
-        if ((i >> 6) != lot_at) {
-          lot_at = i >> 6;
-          const uint32_t k = lot_at * 64u + ((uint32_t)tid & 63u);
-          const uint32_t mk_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)marks, (int)lot_at),
-                         mk_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(marks >> 32), (int)lot_at);
-          const uint32_t mk = (k & 32u) ? mk_hi : mk_lo;
-          lot = PrimHit{0, 0.0, 0.0, 0, 0};
-          lot_scale = 0.0;
-          if (k < n_leaves && ((mk >> (k & 31u)) & 1u)) {
-            const gmlrt_leaf* Lk = leaves + k;
-            V3 rd, rp;
-            to_object(Lk->inv_m, ray_o, ray_d, lot_scale, rd, rp);
-            lot = isect_prim(Lk->type, rp, rd);
-          }
-        }
-        const int from = (int)(i & 63u);
-        ph.bits = __builtin_amdgcn_readlane(lot.bits, from);
-        ph.fA = __builtin_amdgcn_readlane(lot.fA, from);
-        ph.fB = __builtin_amdgcn_readlane(lot.fB, from);
-        ph.tA = readlane_f64(lot.tA, from);
-        ph.tB = readlane_f64(lot.tB, from);
-        scale = readlane_f64(lot_scale, from);
-      } else {
-        const gmlrt_leaf* __restrict__ L = leaves + (word & 0x3FFFFFFFu);
-        V3 rd, rp;
-        to_object(L->inv_m, o, d, scale, rd, rp);
-        ph = isect_prim(L->type, rp, rd);
-      }
+      ph = leaf_test(leaves + (word & 0x3FFFFFFFu), o, d, scale);
       uint32_t n = 0;
       // a list that starts with Exit never raises its operand's counter above zero
       // (primitives.rs:254-293 start both counters at 0): same as no list at all

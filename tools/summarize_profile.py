@@ -19,7 +19,7 @@ shutil.copy(stats[0], os.path.join(dst, name + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, name + "_bench.json"))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, name + "_bench_under_rocprof.json"))
 
-# Each counter pass runs `bench.py --steps 2 --warmup 1`: three launches that learn the tile hand-out, the warm-up,
+# Each counter pass runs `bench.py --steps 2 --warmup 1`: five launches that learn the tile hand-out, the warm-up,
 # then the two timed ones.  Only those two count (the learning launches are slower by design).
 TIMED = 2
 # the trace run is `bench.py --steps 5 --warmup 1`: the last five launches are the timed ones
@@ -72,7 +72,7 @@ json.dump({
     "kernel_trace": {
         "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
         "render_kernel_ms_per_launch": launch_ms,
-        "note": "launches 1-3 learn the tile hand-out (image order with tile timing, then two trials) and launch 4 is the warm-up; "
+        "note": "launches 1-5 learn the tile hand-out (image order with tile timing, then up to four trials) and launch 6 is the warm-up; "
                 "the kernel-stats average covers all of them, the bench's HIP events only the timed five",
         "mean_of_timed_launches_ms": round(sum(launch_ms[-5:]) / 5, 4),
         "hip_event_mean_ms_same_run": under_trace["roofline"]["kernel_ms"]},
