@@ -179,7 +179,8 @@ typedef struct gmlrt_stats {
   double total_ms;       /* host wall time of the call                               */
   uint32_t tiles_shared; /* 8x8-pixel tiles of this launch that four waves rendered together (0 on most launches) */
   uint32_t handout_way;  /* how the launch dealt its tiles (gmlrt_render_device's note): 0 no costs known, 1 learnt order,
-                            2 image order in cost-balanced batches, 3 learnt order with shared tiles, 4 rays regrouped */
+                            2 image order in cost-balanced batches, 3 learnt order with shared tiles, 4 rays regrouped
+                            within a block, 5 level by level (GMLRT_LEVELS=1), 6 sampled (GMLRT_SAMPLED=1); 4 to 6 only on request */
   uint64_t hits;         /* view rays (primary or reflect) that hit a surface and were shaded */
   uint32_t n_gpus;
   uint32_t surface_errors; /* non-zero: some shaded hit raised GMLRT_SOP_TRAP (the call returns GMLRT_ERR_SURFACE) */
@@ -226,10 +227,10 @@ void gmlrt_scene_destroy(gmlrt_scene* s);
  * may be NULL).  Work is queued on `hip_stream` (a hipStream_t, NULL = default
  * stream) and the call returns after the kernel has finished; stats as above.
  * A handle tunes itself to the frames it is asked for: the first call with a given
- * size, depth, field of view and partition times the pixel tiles, the next two or three
+ * size, depth, field of view and partition times the pixel tiles, the next two to four
  * try other ways of handing them out (the dearest first; cost-balanced batches in image
  * order; when single tiles are dear enough to set the length of the launch, those tiles
- * rendered first by four waves each), and from then on the fastest is used (on a frame
+ * rendered first by four waves each, tried twice), and from then on the fastest is used (on a frame
  * whose tiles differ much in cost the first call takes up to 1.7 times as long as the
  * later ones).  The images are the same whichever way; gmlrt_stats.handout_way names it. */
 int gmlrt_render_device(gmlrt_scene* s, const gmlrt_params* params, void* d_rgb8, void* d_rgbf64,
