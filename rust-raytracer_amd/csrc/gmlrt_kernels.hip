@@ -554,13 +554,6 @@ __device__ inline uint32_t merge_any(uint32_t rule, double* __restrict__ evD, ui
   return out;
 }
 
-// Node::intersect of the whole scene for one ray per lane, every operator evaluated
-// with full lists; returns the first element of the root list (all that
-// raytracer.rs:52-58, 74-79 look at).  This is the complete algorithm; the kernel
-// normally runs intersect_first below and comes here only for the rare ray it flags.
-// `lens` holds, per operand-stack level and lane, the length of that list; bit 15
-// marks a two-event primitive list shorter than 1e-10 (it vanishes in any operator
-// whose other operand is empty, primitives.rs:295-298).
 __device__ inline double readlane_f64(double v, int j) {
   const uint64_t u = __builtin_bit_cast(uint64_t, v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), j);
@@ -589,6 +582,13 @@ __device__ __noinline__ bool leaf_look(const gmlrt_leaf* L, V3 o, V3 d) {
   return prim_may_enter(L->type, rp, td, vdot(td, td));
 }
 constexpr uint32_t kMarkLeavesFrom = 24;  // scenes with fewer leaves: the walk alone is shorter than the marking
+// Node::intersect of the whole scene for one ray per lane, every operator evaluated
+// with full lists; returns the first element of the root list (all that
+// raytracer.rs:52-58, 74-79 look at).  This is the complete algorithm; the kernel
+// normally runs intersect_first below and comes here only for the rare ray it flags.
+// `lens` holds, per operand-stack level and lane, the length of that list; bit 15
+// marks a two-event primitive list shorter than 1e-10 (it vanishes in any operator
+// whose other operand is empty, primitives.rs:295-298).
 __device__ __noinline__ Hit intersect_general(const gmlrt_leaf* __restrict__ leaves_v, const uint32_t* __restrict__ nodes_v,
                                               const gmlrt_bound* __restrict__ bounds_v, uint32_t n_nodes,
                                               uint32_t n_leaves, bool active, bool no_bounds, V3 o, V3 d, double* __restrict__ evD_v,
