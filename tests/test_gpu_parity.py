@@ -608,8 +608,8 @@ def test_random_scenes_match_oracle(gmlrt, oracle, first, lattice):
 def test_every_ray_by_the_full_list_algorithm(gmlrt, oracle, monkeypatch, lattice):
     # The kernel's second tracer (every operator of the tree evaluated with full lists, no bounds: the path of the rays
     # in the reference's special cases and of the 1e-10 slivers under the root) normally sees one ray in 10^5.  Here
-    # every ray of forty random scenes, of the chess scene (261 leaves: leaves marked beforehand, subtrees without a
-    # marked leaf jumped over) and of a scene below the size at which leaves are marked goes through it.
+    # every ray of forty random scenes, of three configuration scenes (leaves marked beforehand, subtrees without a
+    # marked leaf jumped over) and of scenes below the size at which leaves are marked goes through it.
     import random_scenes
     monkeypatch.setenv("GMLRT_ALL_RAYS_WITHOUT_BOUNDS", "1")
     texts = [random_scenes.scene_text(seed, 65, 49, 3, lattice=lattice) for seed in range(300, 340)]
@@ -617,8 +617,11 @@ def test_every_ray_by_the_full_list_algorithm(gmlrt, oracle, monkeypatch, lattic
         texts += [open(os.path.join(SCENES, n + ".gml")).read() for n in ("snowgoon", "dice", "golf")]
     calls = [(gmlrt.Program(text=t).calls[0], oracle.OracleProgram(text=t), 0) for t in texts]
     if not lattice:
-        chess = os.path.join(SCENES, "chess.gml")
-        calls.append((gmlrt.Program(path=chess).calls[0].with_overrides(240, 135, 3), oracle.OracleProgram(path=chess), (240, 135, 3)))
+        # (chess: 261 leaves under a long chain of unions; fractal: 586 leaves, 19 words of marks, bound words nested
+        # seven deep; cone-fractal: cones and cylinders only)
+        for name, over in (("chess", (240, 135, 3)), ("fractal", (120, 67, 2)), ("cone-fractal", (160, 90, 3))):
+            path = os.path.join(SCENES, name + ".gml")
+            calls.append((gmlrt.Program(path=path).calls[0].with_overrides(*over), oracle.OracleProgram(path=path), over))
     for k, (call, orc, over) in enumerate(calls):
         img, _, st = gmlrt.render(call)
         ref, _, cnt = orc.render(0, threads=8) if over == 0 else orc.render(0, w=over[0], h=over[1], depth=over[2], threads=8)
