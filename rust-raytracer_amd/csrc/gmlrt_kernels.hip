@@ -2521,6 +2521,12 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   A.next_batch = (unsigned int*)d_counters;
   A.block_counts = (unsigned long long*)(d_counters + kOffBlockCounts);
   A.diag = (unsigned long long*)(d_counters + kOffDiag);
+  // The ray counts of the blocks and the surface-error word go straight to page-locked host memory (every block
+  // stores its four counts once, at its end): no copy behind the kernel, one operation less for the stream to start
+  // and finish in every launch.  (Level by level the counts add up over several launches: on the device.)
+  static const bool counts_to_host = [] { const char* e = std::getenv("GMLRT_COUNTS_TO_HOST"); return !e || *e != '0'; }();  // tuning runs
+  const bool zero_copy = counts_to_host && !levels;
+  if (zero_copy) A.block_counts = (unsigned long long*)((uint8_t*)s->h_staging + 1024);
 
   // (with the static scratch this clears what the previous call on this device left in the counters)
   HIP_TRY(hipMemsetAsync(d_counters, 0, kOffShadeArgs, stream));  // claim and diagnostic counters; every block writes its counts
@@ -2540,7 +2546,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   SA.consts = d_consts;
   SA.leaf_surf = (const uint32_t*)s->d_leaf_surf;
   SA.surf_prog = (const SurfInstr*)s->d_surf;
-  SA.surf_error = (uint32_t*)(d_counters + kOffSurfError);
+  SA.surf_error = zero_copy ? (uint32_t*)((uint8_t*)s->h_staging + 1024 - 8) : (uint32_t*)(d_counters + kOffSurfError);
   SA.ctx = A.ctx;
   SA.c_x = A.c_x; SA.c_y = A.c_y; SA.pw = A.pw;
   SA.axes = A.axes; SA.n_axes = A.n_axes; SA.n_cone_forms = A.n_cone_forms;
@@ -2566,6 +2572,7 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
 #endif
   // (the whole slot: the zeros behind the record clear the surface-error word of the previous launch)
   std::memset(s->h_staging, 0, kOffBlockCounts - kOffShadeArgs);
+  if (zero_copy) *(unsigned long long*)((uint8_t*)s->h_staging + 1024 - 8) = 0ull;  // (the word the lanes themselves write, then)
   std::memcpy(s->h_staging, &SA, sizeof(SA));
   HIP_TRY(hipMemcpyAsync(d_counters + kOffShadeArgs, s->h_staging, kOffBlockCounts - kOffShadeArgs, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_start, stream));
@@ -2653,8 +2660,9 @@ std::string dev_render(DeviceScene* s, const gmlrt_params& p, void* d_rgb8, void
   HIP_TRY(hipEventRecord((hipEvent_t)s->ev_stop, stream));
   // the surface-error word and, right behind it, the per-block ray counts
   const unsigned long long* per_block = (const unsigned long long*)((uint8_t*)s->h_staging + 1024);
-  HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 8, d_counters + kOffSurfError, 8 + (size_t)grid * 4 * sizeof(unsigned long long),
-                         hipMemcpyDeviceToHost, stream));
+  if (!zero_copy)
+    HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 8, d_counters + kOffSurfError, 8 + (size_t)grid * 4 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, stream));
   *(uint32_t*)((uint8_t*)s->h_staging + 1024 - 16) = 0;
   if (levels) HIP_TRY(hipMemcpyAsync((uint8_t*)s->h_staging + 1024 - 16, (uint32_t*)s->d_qcnt + kQcOverflow, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
